@@ -1,0 +1,207 @@
+/*
+ * zgpt2.h — C ABI of libzgpt2_hip.so: the MI355X (gfx950) implementation of zig_gpt2's forward
+ * hot path.  This is the drop-in boundary: every entry point below replaces one public decl of
+ * the reference's src/ops.zig (op tier) or one method of src/main.zig (model tier); the Zig shim
+ * zig_gpt2_amd/zig/ops.zig keeps the reference's decl signatures and forwards each slice as
+ * (ptr, len).  Citations are file:line in /root/reference (EugenHotaj/zig_gpt2 @ v1).
+ *
+ * Conventions
+ *   - All functions return 0 on success, a negative zg_status otherwise; zg_last_error() gives
+ *     text.  The reference's ops return void and rely on Zig slice bounds checks; the length
+ *     checks those imply are done here and reported as ZG_ERR_SHAPE.
+ *   - Lengths are ELEMENT counts (Zig slice .len), not bytes.  f32 is IEEE binary32, usize is
+ *     size_t (8 bytes).
+ *   - Op tier: every pointer may be host memory or device memory (detected with
+ *     hipPointerGetAttributes).  Host buffers are staged through an arena that is allocated once
+ *     in zg_init — no *_forward call allocates device or host memory (the reference's
+ *     "no allocations at runtime" contract, README.md:6, src/main.zig:46-64).  Op-tier calls are
+ *     synchronous on return, because the reference's host code reads the buffers next
+ *     (src/main.zig:136-145).
+ *   - Model tier: weights, KV cache and every scratch buffer live in one device arena created by
+ *     zg_gpt_create; zg_gpt_forward/zg_gpt_generate_greedy only launch kernels.
+ *   - Single-threaded like the reference: one call at a time per process.
+ */
+#ifndef ZGPT2_H
+#define ZGPT2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ZG_OK = 0,
+    ZG_ERR_NOT_INITIALIZED = -1,
+    ZG_ERR_SHAPE = -2,      /* a slice length does not match the shapes implied by the call */
+    ZG_ERR_HIP = -3,        /* a HIP runtime call failed (text in zg_last_error) */
+    ZG_ERR_STAGING = -4,    /* host buffers of one call exceed the staging arena */
+    ZG_ERR_UNSUPPORTED = -5,
+    ZG_ERR_ARG = -6
+} zg_status;
+
+/* ------------------------------------------------------------------ runtime ---------------- */
+
+/* Select the device, create the stream and the host-staging arena (default 512 MiB, or
+ * ZGPT2_STAGING_MB).  Idempotent. */
+int zg_init(int device);
+int zg_init_ex(int device, size_t staging_bytes);
+int zg_shutdown(void);
+const char* zg_last_error(void);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the library's
+ * own stream. */
+int zg_set_stream(void* hip_stream);
+int zg_synchronize(void);
+/* Upload a host tensor once and keep a device mirror keyed by its host address: later op-tier
+ * calls that receive the same host pointer use the mirror instead of re-staging it (weights are
+ * borrowed for the life of the arena in the reference, src/main.zig:349-351). */
+int zg_register_tensor(const float* host_ptr, size_t len);
+int zg_unregister_all(void);
+
+/* ------------------------------------------------------------------ op tier: src/ops.zig --- */
+
+/* Linear.forward — src/ops.zig:21-46.  weight is [out_features, in_features] row-major (the
+ * reference's "column major", ops.zig:9); bias may be NULL; batch = inputs_len / in_features
+ * (ops.zig:22); outputs [batch, out_features]. */
+int zg_linear_forward(size_t in_features, size_t out_features, const float* weight,
+                      const float* bias_or_null, const float* inputs, size_t inputs_len,
+                      float* outputs, size_t outputs_len);
+
+/* Embedding.forward — src/ops.zig:59-67.  weight [n_rows, emb_dim]; idxs are usize. */
+int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len,
+                         const size_t* idxs, size_t idxs_len, float* embeddings,
+                         size_t embeddings_len);
+
+/* LayerNorm.forward — src/ops.zig:82-104.  In place over inputs_len / n_features rows;
+ * std = sqrt(E[x^2] - E[x]^2 + eps) (ops.zig:95). */
+int zg_layernorm_forward(size_t n_features, const float* weight, const float* bias, float eps,
+                         float* inputs, size_t inputs_len);
+
+/* CausalSelfAttention.forward — src/ops.zig:129-173: one decode step with a caller-owned KV
+ * cache, batch 1.  k_cache / v_cache are the caller's [seq_len, n_embed] slices (row t = token
+ * t); row seq_len-1 is written by this call (ops.zig:152,157).  _qkv [3E], _q [E], _k/_v
+ * [seq_len*E], _attn [seq_len] are the reference's scratch slices; on return _qkv holds the
+ * c_attn output and _q the merged heads (ops.zig:171) as in the reference, while _k/_v/_attn
+ * (pure scratch whose content no caller reads) are left untouched: the kernel attends over the
+ * [T, H, hd] cache in place instead of re-transposing it every step (ops.zig:153,158). */
+int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight,
+                    const float* c_attn_bias, const float* c_proj_weight, const float* c_proj_bias,
+                    size_t seq_len, const float* inputs, size_t inputs_len, float* k_cache,
+                    size_t k_cache_len, float* v_cache, size_t v_cache_len, float* outputs,
+                    size_t outputs_len, float* _qkv, size_t _qkv_len, float* _q, size_t _q_len,
+                    float* _k, size_t _k_len, float* _v, size_t _v_len, float* _attn,
+                    size_t _attn_len);
+
+/* CausalSelfAttention.split_qkv — src/ops.zig:177-196: [B, T, 3E] -> [B, T, E]. */
+int zg_split_qkv(size_t n_embed, size_t seq_len, const float* inputs, size_t inputs_len,
+                 size_t split_idx, float* outputs, size_t outputs_len);
+
+/* CausalSelfAttention.transpose — src/ops.zig:199-216: (b, t, n, h) -> (b, n, t, h). */
+int zg_transpose(size_t seq_len, size_t n_heads, size_t head_dim, const float* inputs,
+                 size_t inputs_len, float* outputs, size_t outputs_len);
+
+/* scaled_dot_product_attention — src/ops.zig:249-307.  q [B,H,1,hd], k/v [B,H,T,hd],
+ * outputs [B,H,1,hd]; B = k_len / (H*T*hd) (ops.zig:259); _attn_len must be >= seq_len. */
+int zg_scaled_dot_product_attention(const float* q, size_t q_len, const float* k, size_t k_len,
+                                    const float* v, size_t v_len, size_t n_heads, size_t seq_len,
+                                    size_t head_dim, float* outputs, size_t outputs_len,
+                                    float* _attn, size_t _attn_len);
+
+/* gelu — src/ops.zig:221-228, in place. */
+int zg_gelu(float* inputs, size_t inputs_len);
+
+/* softmax — src/ops.zig:231-241, in place; the whole slice is one vector. */
+int zg_softmax(float* inputs, size_t inputs_len);
+
+/* ------------------------------------------------------------------ model tier: src/main.zig */
+
+/* GPTConfig — src/main.zig:5-23, field for field. */
+typedef struct {
+    size_t vocab_size;
+    size_t context_size;
+    size_t n_layer;
+    size_t n_heads;
+    size_t n_embed;
+} zg_gpt_config;
+
+typedef struct zg_gpt zg_gpt;
+
+enum {
+    ZG_GPT_WEIGHTS_BF16 = 0,     /* Linear/embedding matrices stored bf16 (RNE) — default */
+    ZG_GPT_WEIGHTS_F32 = 1 << 0, /* keep matrices in fp32 (exact with arbitrary checkpoints) */
+    ZG_GPT_NO_GRAPH = 1 << 1,    /* launch kernels eagerly instead of replaying a hipGraph */
+    ZG_GPT_KV_F16 = 1 << 2       /* store the KV cache as fp16 instead of fp32 */
+};
+
+/* Per-block tensor slots (load_block, src/main.zig:271-302) and top-level slots (load_gpt,
+ * src/main.zig:304-314).  Linear weights are [out, in] like ops.Linear.weight. */
+enum {
+    ZG_LN_1_G = 0, ZG_LN_1_B, ZG_C_ATTN_W, ZG_C_ATTN_B, ZG_C_PROJ_W, ZG_C_PROJ_B,
+    ZG_LN_2_G, ZG_LN_2_B, ZG_C_FC_W, ZG_C_FC_B, ZG_MLP_PROJ_W, ZG_MLP_PROJ_B, ZG_N_BLOCK_SLOTS
+};
+enum { ZG_WTE = 0, ZG_WPE, ZG_LN_F_G, ZG_LN_F_B, ZG_N_TOP_SLOTS };
+
+/* State.init + load_gpt's allocations (src/main.zig:46-64, :298-299): one device arena holding
+ * weights, `batch` private KV caches and all scratch.  batch = number of independent prompts
+ * decoded in lock step (the reference supports 1, src/ops.zig:126-128). */
+int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsigned flags);
+int zg_gpt_destroy(zg_gpt* g);
+
+/* Weight upload (replaces load_linear/load_layer_norm/load_embedding, src/main.zig:210-269).
+ * src is fp32, host or device; matrices are converted to the arena's storage type on device. */
+int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src, size_t len);
+int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len);
+
+/* The weight region of the arena (for an RCCL broadcast to the other GPUs of a node). */
+int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes);
+/* Bytes one decode step must read at sequence length T: weights + KV. */
+int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* kv_bytes);
+
+/* GPT.forward — src/main.zig:178-195, for all `batch` sequences at once: tokens[b] is fed at
+ * position seq_len-1.  If logits_out != NULL (host or device, [batch, vocab]) it receives
+ * state.logits and the call is synchronous; compute_logits == 0 skips lm_head (main.zig:192). */
+int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens,
+                   int compute_logits, float* logits_out, size_t logits_len);
+/* argmax of the logits of the last zg_gpt_forward(compute_logits=1) per sequence (lowest index
+ * wins ties) — the greedy replacement for GPT.sample (src/main.zig:198-207). */
+int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens);
+/* ln_f output of the last forward, [batch, n_embed] (state.x, main.zig:189). */
+int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len);
+
+/* generate — src/main.zig:322-342 with greedy argmax instead of the sampler, for `batch`
+ * prompts in lock step.  prompts is [batch, prompt_stride] (usize), prompt_lens[b] >= 1 tokens
+ * are used from row b.  Runs n_steps (<= context_size; the reference always runs context_size,
+ * main.zig:330) decode steps without any host round trip per token; out_tokens [batch, n_steps]
+ * receives the token after every step (prompt tokens included, main.zig:339-340).
+ * As in the reference the last prompt token is fed twice (main.zig:334,337). */
+int zg_gpt_generate_greedy(zg_gpt* g, const size_t* prompts, size_t prompt_stride,
+                           const size_t* prompt_lens, size_t n_steps, size_t* out_tokens,
+                           size_t out_len);
+/* Asynchronous form used by the benchmark: enqueue the same n_steps on the stream and return;
+ * results stay on the device until zg_gpt_generate_fetch. */
+int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride,
+                            const size_t* prompt_lens, size_t n_steps);
+int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t out_len);
+
+/* ------------------------------------------------------------------ measurement helpers ---- */
+
+/* Run only the lm_head kernel (ln_f + 50257x768 GEMV + argmax) `iters` times on the current
+ * state and return the average device time per launch in microseconds (HIP events on the
+ * library stream).  Used by bench.py's roofline line. */
+int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes);
+enum { ZG_TIME_LM_HEAD = 0, ZG_TIME_C_FC = 1, ZG_TIME_ATTN = 2, ZG_TIME_STEP = 3 };
+
+/* Run `iters` consecutive decode steps starting at sequence length seq_len as EAGER launches with a
+ * HIP event between every two kernels, and return the average device time in microseconds that
+ * one step spends per kernel class (classes 1-5 summed over the layers):
+ *   [0] token select + embedding   [1] ln_1 + c_attn + KV append   [2] decode attention
+ *   [3] head merge + attn c_proj + residual   [4] ln_2 + c_fc + gelu   [5] mlp c_proj + residual
+ *   [6] ln_f + lm_head + argmax     [7] sum of all intervals.
+ * Intervals are event-to-event, so each includes the boundary to the next kernel. */
+int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, size_t n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZGPT2_H */

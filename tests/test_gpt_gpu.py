@@ -1,0 +1,145 @@
+"""Model-tier parity on a real MI355X: the device-resident GPT (zg_gpt_*) vs the golden vectors of
+the reference's PyTorch GPT (tests/golden/gpt_*.npz) and vs the CPU oracle on seeded inputs.
+
+Tolerance (north_star): logits within 1e-3 relative of the fp32 reference on the same
+(bf16-representable) weights — golden_io.assert_model_close; greedy token ids identical.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from golden_io import assert_greedy_ids_match, assert_model_close, load_gpt
+from zig_gpt2_amd import gpt as zgpt
+from zig_gpt2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make(cfg, seed, **kw):
+    w = synth.make_weights(cfg, seed=seed, bf16=True)
+    m = zgpt.GPT(cfg, **kw)
+    m.load_weights(w)
+    return m, w
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "nano-char", "124M"])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_generate_matches_reference_gpt(zg, name, use_graph):
+    cfg, g = load_gpt(name)
+    m, _ = make(cfg, int(g["weight_seed"]), use_graph=use_graph)
+    n_steps, n_prompt = len(g["out_tokens"]), len(g["prompt"])
+    ids = m.generate([g["prompt"]], n_steps)[0]
+    assert np.array_equal(ids[:n_prompt], g["prompt"])
+    assert_greedy_ids_match(g["out_tokens"][n_prompt:], ids[n_prompt:], g["top1"], g["top2"], name)
+    # teacher-forced logits through GPT.forward
+    worst = 0.0
+    for s in range(n_steps):
+        lg = m.forward(s + 1, [g["fed"][s]], compute_logits=s >= n_prompt)
+        if s >= n_prompt:
+            worst = max(worst, assert_model_close(g["logits"][s - n_prompt], lg[0, g["logit_cols"]], f"{name} step {s}"))
+            assert int(m.argmax()[0]) == int(np.argmax(lg[0]))
+    print(f"{name}: worst normalised rel err vs reference GPT {worst:.2e}")
+    m.close()
+
+
+def test_fp32_weight_mode_matches_oracle(zg):
+    cfg = synth.CONFIGS["tiny3"]
+    w = synth.make_weights(cfg, seed=5, bf16=False)  # not bf16-representable: needs ZG_GPT_WEIGHTS_F32
+    m = zgpt.GPT(cfg, weights_f32=True)
+    m.load_weights(w)
+    ref = oracle.GPT(cfg, w)
+    prompt = synth.rand_tokens(9, 3, cfg.vocab_size)
+    ids_ref, lg_ref = ref.generate_greedy(prompt, cfg.context_size, want_logits=True)
+    ids = m.generate([prompt], cfg.context_size)[0]
+    top = np.sort(lg_ref, axis=1)
+    assert_greedy_ids_match(ids_ref[3:], ids[3:], top[:, -1], top[:, -2], "fp32 weights")
+    m.close()
+
+
+@pytest.mark.parametrize("batch", [2, 3, 8])
+def test_batched_prompts_match_independent_oracle_runs(zg, batch):
+    """The build's extension of ops.zig:126-128: `batch` prompts of different lengths decoded in lock
+    step must equal `batch` independent reference-style generations."""
+    cfg = synth.CONFIGS["tiny"]
+    m, w = make(cfg, 21, batch=batch)
+    prompts = [synth.rand_tokens(100 + b, 1 + (b * 3) % 5, cfg.vocab_size) for b in range(batch)]
+    n_steps = cfg.context_size
+    ids = m.generate(prompts, n_steps)
+    for b in range(batch):
+        ref = oracle.GPT(cfg, w)
+        ids_ref, lg = ref.generate_greedy(prompts[b], n_steps, want_logits=True)
+        top = np.sort(lg, axis=1)
+        n = len(prompts[b])
+        assert np.array_equal(ids[b, :n], prompts[b])
+        assert_greedy_ids_match(ids_ref[n:], ids[b, n:], top[:, -1], top[:, -2], f"row {b}")
+    # forced-token forward, all rows at once
+    toks = [int(p[0]) for p in prompts]
+    lg = m.forward(1, toks)
+    for b in range(batch):
+        ref = oracle.GPT(cfg, w)
+        assert_model_close(ref.forward(1, toks[b]), lg[b], f"row {b} logits")
+    m.close()
+
+
+def test_full_context_nano_char_vs_oracle(zg):
+    cfg = synth.CONFIGS["nano-char"]
+    m, w = make(cfg, 31)
+    ref = oracle.GPT(cfg, w)
+    prompt = synth.rand_tokens(32, 2, cfg.vocab_size)
+    ids_ref, lg = ref.generate_greedy(prompt, cfg.context_size, want_logits=True)
+    ids = m.generate([prompt], cfg.context_size)[0]
+    top = np.sort(lg, axis=1)
+    assert_greedy_ids_match(ids_ref[2:], ids[2:], top[:, -1], top[:, -2], "nano-char 256 ctx")
+    m.close()
+
+
+def test_124m_long_context_properties(zg):
+    """Full BASELINE size (124M, 1024 ctx): size-independent properties + an oracle spot check.
+    (a) graph replay == eager launches, token for token; (b) a batch of identical prompts yields
+    identical rows; (c) the first 96 steps equal the CPU oracle; (d) hidden state stays finite."""
+    cfg = synth.CONFIGS["124M"]
+    w = synth.make_weights(cfg, seed=0, bf16=True)
+    prompt = synth.rand_tokens(77, 1, cfg.vocab_size)
+    a = zgpt.GPT(cfg, use_graph=True)
+    a.load_weights(w)
+    ids_graph = a.generate([prompt], cfg.context_size)[0]
+    assert np.isfinite(a.hidden()).all()
+    a.close()
+    b = zgpt.GPT(cfg, use_graph=False, batch=2)
+    b.load_weights(w)
+    ids_eager = b.generate([prompt, prompt], cfg.context_size)
+    b.close()
+    assert np.array_equal(ids_eager[0], ids_eager[1])
+    assert np.array_equal(ids_graph, ids_eager[0])
+    ref = oracle.GPT(cfg, w)
+    n = 96
+    ids_ref, lg = ref.generate_greedy(prompt, n, want_logits=True)
+    top = np.sort(lg, axis=1)
+    assert_greedy_ids_match(ids_ref[1:], ids_graph[1:n], top[:, -1], top[:, -2], "124M first 96 steps")
+    assert ids_graph.max() < cfg.vocab_size
+
+
+def test_kv_f16_mode_stays_close(zg):
+    cfg = synth.CONFIGS["tiny"]
+    m, w = make(cfg, 41, kv_f16=True)
+    ref = oracle.GPT(cfg, w)
+    toks = synth.rand_tokens(42, cfg.context_size, cfg.vocab_size)
+    lg_ref = ref.forced_logits(toks, 0)
+    for s in range(cfg.context_size):
+        lg = m.forward(s + 1, [toks[s]])
+        assert_model_close(lg_ref[s], lg[0], f"kv f16 step {s}", rtol=2e-3)
+    m.close()
+
+
+def test_model_tier_errors(zg):
+    from zig_gpt2_amd import _lib
+
+    cfg = synth.CONFIGS["tiny"]
+    m = zgpt.GPT(cfg)
+    with pytest.raises(_lib.ZgError):
+        m.forward(cfg.context_size + 1, [0])
+    with pytest.raises(_lib.ZgError):
+        m.forward(1, [cfg.vocab_size])
+    with pytest.raises(_lib.ZgError):
+        zgpt.GPT(synth.GPTConfig(100, 16, 1, 3, 96))  # head_dim 32
+    m.close()

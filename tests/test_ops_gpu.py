@@ -1,0 +1,221 @@
+"""Op-tier parity on a real MI355X, through the C ABI (zig_gpt2_amd.ops -> libzgpt2_hip.so).
+
+The first block replays the 8 tests of the reference's src/tests.zig on the committed golden
+vectors (tests/golden/ops.npz, produced by the reference's generate_test_data.py) at the reference
+tolerance (src/tests.zig:4-20).  The second block compares against the CPU oracle on seeded inputs
+over shapes / edge cases the reference's tests do not reach.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from golden_io import assert_ref_close, load_ops
+from zig_gpt2_amd import _lib, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    return load_ops()
+
+
+def z(*shape):
+    return np.zeros(shape, np.float32)
+
+
+# ------------------------------------------------------------------ src/tests.zig, test by test
+def test_linear_golden(zg, g):  # src/tests.zig:22-78
+    y = z(3, 3072)
+    ops.Linear(768, 3072, g["linear_weight"], g["linear_bias"]).forward(g["linear_inputs"], y)
+    assert_ref_close(g["linear_outputs"], y, "Linear")
+    y2 = z(3, 3072)
+    ops.Linear(768, 3072, g["linear_weight"], None).forward(g["linear_inputs"], y2)
+    assert_ref_close(g["linear_outputs_no_bias"], y2, "Linear no bias")
+
+
+def test_embedding_golden(zg, g):  # src/tests.zig:80-114
+    y = z(3, 768)
+    ops.Embedding(768, g["embedding_weight"]).forward(g["embedding_inputs"].astype(np.uint64), y)
+    assert_ref_close(g["embedding_outputs"], y, "Embedding")
+    assert np.array_equal(y, g["embedding_outputs"])  # a gather is bit-exact
+
+
+def test_layernorm_golden(zg, g):  # src/tests.zig:116-155
+    x = g["layer_norm_inputs"].copy()
+    ops.LayerNorm(768, g["layer_norm_weight"], g["layer_norm_bias"]).forward(x)
+    assert_ref_close(g["layer_norm_outputs"], x, "LayerNorm")
+
+
+def test_split_qkv_golden(zg, g):  # src/tests.zig:157-209
+    attn = ops.CausalSelfAttention(12, 768, None, None)
+    for i, n in enumerate(["split_q", "split_k", "split_v"]):
+        y = z(1, 5, 768)
+        attn.split_qkv(5, g["split_inputs"], i, y)
+        assert np.array_equal(y, g[n]), n
+
+
+def test_transpose_golden(zg, g):  # src/tests.zig:211-243
+    y = z(1, 12, 5, 64)
+    ops.CausalSelfAttention.transpose((5, 12, 64), g["transpose_inputs"], y)
+    assert np.array_equal(y, g["transpose_outputs"])
+
+
+def test_attn_forward_golden(zg, g):  # src/tests.zig:245-334: incremental decode vs causal attention
+    e, T = 768, 5
+    attn = ops.CausalSelfAttention(12, e, ops.Linear(e, 3 * e, g["attn_c_attn_weight"], g["attn_c_attn_bias"]),
+                                   ops.Linear(e, e, g["attn_c_proj_weight"], g["attn_c_proj_bias"]))
+    k_cache, v_cache, actual = z(T * e), z(T * e), z(T, e)
+    _qkv, _q, _k, _v, _attn = z(3 * e), z(e), z(T * e), z(T * e), z(T)
+    for s in range(T):
+        attn.forward(s + 1, g["attn_inputs"][0, s], k_cache[: (s + 1) * e], v_cache[: (s + 1) * e], actual[s],
+                     _qkv, _q, _k[: (s + 1) * e], _v[: (s + 1) * e], _attn[: s + 1])
+        assert_ref_close(g["attn_outputs"][0, s], actual[s], f"attn step {s}")
+
+
+def test_sdpa_golden(zg, g):  # fixtures the reference generates but never tests
+    q, k, v, exp = (g[n][0] for n in ("sdpa_q", "sdpa_k", "sdpa_v", "sdpa_outputs"))
+    for s in range(5):
+        y = z(12, 64)
+        ops.scaled_dot_product_attention(np.ascontiguousarray(q[:, s]), np.ascontiguousarray(k[:, : s + 1]),
+                                         np.ascontiguousarray(v[:, : s + 1]), 12, s + 1, 64, y, z(s + 1))
+        assert_ref_close(exp[:, s], y, f"sdpa step {s}")
+
+
+def test_gelu_golden(zg, g):  # src/tests.zig:336-360
+    x = g["gelu_inputs"].copy()
+    ops.gelu(x)
+    assert_ref_close(g["gelu_outputs"], x, "gelu")
+
+
+def test_softmax_golden(zg, g):  # src/tests.zig:362-388: row by row
+    x = g["softmax_inputs"].copy()
+    for b in range(3):
+        ops.softmax(x[b])
+    assert_ref_close(g["softmax_outputs"], x, "softmax")
+
+
+# ------------------------------------------------------------------ seeded sweeps vs the oracle
+@pytest.mark.parametrize("m,k,n", [(1, 768, 2304), (1, 3072, 768), (3, 768, 3072), (8, 768, 768), (9, 384, 1152),
+                                   (17, 128, 65), (1, 1600, 4800), (2, 6400, 1600), (5, 1536, 384), (1, 768, 50257),
+                                   (4, 100, 37), (1, 8, 1), (2, 64, 3)])
+def test_linear_sweep(zg, m, k, n):
+    w = synth.fill_normal(100 + n, n * k, 0, 0.05).reshape(n, k)
+    b = synth.fill_normal(200 + n, n, 0, 0.05)
+    x = synth.fill_normal(300 + m, m * k, 0, 1.0).reshape(m, k)
+    y = z(m, n)
+    ops.Linear(k, n, w, b).forward(x, y)
+    assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n}")
+
+
+def test_linear_registered_weight_and_device_pointers(zg):
+    import torch
+
+    k, n, m = 768, 1000, 2
+    w = synth.fill_normal(1, n * k, 0, 0.05).reshape(n, k)
+    x = synth.fill_normal(2, m * k).reshape(m, k)
+    exp = oracle.linear_forward(k, n, w, None, x)
+    _lib.check(zg.zg_register_tensor(w.ctypes.data, w.size))
+    y = z(m, n)
+    ops.Linear(k, n, w, None).forward(x, y)
+    assert_ref_close(exp, y, "registered weight")
+    _lib.check(zg.zg_unregister_all())
+    wd, xd = torch.from_numpy(w).cuda(), torch.from_numpy(x).cuda()
+    yd = torch.zeros(m, n, device="cuda")
+    ops.Linear(k, n, wd, None).forward(xd, yd)
+    assert_ref_close(exp, yd.cpu().numpy(), "device pointers")
+
+
+@pytest.mark.parametrize("rows,n", [(1, 768), (3, 768), (7, 1600), (2, 384), (1, 5), (5, 64)])
+def test_layernorm_sweep(zg, rows, n):
+    gam = synth.fill_normal(5, n, 1.0, 0.1)
+    bet = synth.fill_normal(6, n, 0.0, 0.1)
+    x = synth.fill_normal(7 + rows, rows * n, 0.3, 2.0).reshape(rows, n)
+    y = x.copy()
+    ops.LayerNorm(n, gam, bet).forward(y)
+    assert_ref_close(oracle.layernorm_forward(n, gam, bet, x), y, "LayerNorm")
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 768, 1024, 50257])
+def test_softmax_sweep(zg, n):
+    x = synth.fill_normal(40 + n, n, 0.0, 3.0)
+    y = x.copy()
+    ops.softmax(y)
+    assert_ref_close(oracle.softmax(x), y, f"softmax {n}")
+    assert abs(float(y.sum(dtype=np.float64)) - 1.0) < 1e-5
+
+
+def test_gelu_tails_and_sizes(zg):
+    x = np.concatenate([synth.fill_normal(9, 3073, 0, 2.0), np.array([-30, -12, -6, -3, -1e-4, 0, 1e-4, 3, 6, 12, 30], np.float32)])
+    y = x.copy()
+    ops.gelu(y)
+    assert_ref_close(oracle.gelu(x), y, "gelu")
+    assert np.isfinite(y).all()
+
+
+def test_empty_slices_are_noops(zg):
+    e = np.zeros(0, np.float32)
+    ops.gelu(e)
+    ops.softmax(e)
+    ops.LayerNorm(8, np.ones(8, np.float32), np.zeros(8, np.float32)).forward(e)
+    ops.Linear(8, 4, np.zeros((4, 8), np.float32), None).forward(e, e)
+
+
+@pytest.mark.parametrize("b,h,t", [(1, 12, 1), (1, 12, 63), (1, 12, 64), (1, 12, 65), (2, 6, 255), (1, 2, 256),
+                                   (3, 2, 257), (1, 12, 1024), (1, 25, 513)])
+def test_sdpa_sweep(zg, b, h, t):
+    q = synth.fill_normal(50 + t, b * h * 64, 0, 1.0)
+    k = synth.fill_normal(51 + t, b * h * t * 64, 0, 1.0)
+    v = synth.fill_normal(52 + t, b * h * t * 64, 0, 1.0)
+    y = z(b * h * 64)
+    ops.scaled_dot_product_attention(q, k, v, h, t, 64, y, z(t))
+    assert_ref_close(oracle.sdpa(q, k, v, h, t, 64), y, f"sdpa b{b} h{h} t{t}")
+
+
+def test_sdpa_one_dominant_key(zg):
+    """Forces the cross-wave / cross-split max rescale: one key far above the rest, placed in each split."""
+    h, t = 2, 700
+    for hot in (0, 100, 300, 699):
+        q = synth.fill_normal(60, h * 64, 0, 1.0)
+        k = synth.fill_normal(61, h * t * 64, 0, 0.3).reshape(h, t, 64)
+        k[:, hot] = q.reshape(h, 64) * 4.0
+        v = synth.fill_normal(62, h * t * 64, 0, 1.0)
+        y = z(h * 64)
+        ops.scaled_dot_product_attention(q, np.ascontiguousarray(k), v, h, t, 64, y, z(t))
+        assert_ref_close(oracle.sdpa(q, np.ascontiguousarray(k).ravel(), v, h, t, 64), y, f"hot key {hot}")
+
+
+def test_attn_forward_long_incremental(zg):
+    """KV-cache decode over 300 steps (crosses the 256-position split) vs the oracle's step-by-step attention."""
+    e, hds, T = 128, 2, 300
+    caw = synth.fill_normal(70, 3 * e * e, 0, 0.08).reshape(3 * e, e)
+    cab = synth.fill_normal(71, 3 * e, 0, 0.05)
+    cpw = synth.fill_normal(72, e * e, 0, 0.08).reshape(e, e)
+    cpb = synth.fill_normal(73, e, 0, 0.05)
+    xs = synth.fill_normal(74, T * e, 0, 1.0).reshape(T, e)
+    ref = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, T)
+    attn = ops.CausalSelfAttention(hds, e, ops.Linear(e, 3 * e, caw, cab), ops.Linear(e, e, cpw, cpb))
+    k_cache, v_cache = z(T * e), z(T * e)
+    _qkv, _q, _k, _v, _attn = z(3 * e), z(e), z(T * e), z(T * e), z(T)
+    for s in range(T):
+        out = z(e)
+        attn.forward(s + 1, xs[s], k_cache[: (s + 1) * e], v_cache[: (s + 1) * e], out, _qkv, _q,
+                     _k[: (s + 1) * e], _v[: (s + 1) * e], _attn[: s + 1])
+        exp = ref.forward(s + 1, xs[s])
+        if s % 17 == 0 or s in (255, 256, 257, T - 1):
+            assert_ref_close(exp, out, f"step {s}")
+    # the caller-owned caches hold the same rows as the reference's (ops.zig:152,157)
+    assert_ref_close(ref.k_cache, k_cache, "k_cache")
+    assert_ref_close(ref.v_cache, v_cache, "v_cache")
+
+
+def test_error_behaviour(zg):
+    x = z(10)
+    assert zg.zg_layernorm_forward(768, x.ctypes.data, x.ctypes.data, 1e-5, x.ctypes.data, 10) == -2  # ZG_ERR_SHAPE
+    assert b"multiple" in zg.zg_last_error()
+    w = z(4, 8)
+    assert zg.zg_linear_forward(8, 4, w.ctypes.data, None, x.ctypes.data, 8, x.ctypes.data, 3) == -2
+    with pytest.raises(_lib.ZgError):
+        ops.Embedding(8, z(4, 8)).forward(np.array([5], np.uint64), z(8))  # index out of range
+    with pytest.raises(_lib.ZgError):
+        ops.scaled_dot_product_attention(z(32), z(32), z(32), 1, 1, 32, z(32), z(1))  # head_dim != 64

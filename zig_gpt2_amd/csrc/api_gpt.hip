@@ -1,0 +1,642 @@
+// api_gpt.hip — model tier of the C ABI: GPTConfig/State/Block/GPT/generate of the reference's
+// src/main.zig as one device-resident object.  Weights, per-sequence KV caches and all scratch
+// live in a single arena allocated by zg_gpt_create (the State.init / load_gpt moment of the
+// reference); a decode step is a fixed chain of kernels captured once into a hipGraph whose
+// position, tokens and argmax all live in device memory, so a whole greedy generation is enqueued
+// without a host round trip per token.
+//
+// HBM layout (one hipMalloc, 256-B aligned sub-buffers):
+//   [ weights: wte | wpe | ln_f | per layer: c_attn_w c_proj_w c_fc_w mlp_proj_w + fp32 vectors ]
+//   [ KV cache: layer x {K,V} x batch x head x ctx x 64 ]   head-major: one head's keys are one
+//                                                            contiguous [ctx, 64] slab, so no
+//                                                            per-step transpose (ops.zig:153,158)
+//   [ scratch: x q h4 attention partials logits argmax partials, control block, token buffers ]
+#include <string.h>
+
+#include <vector>
+
+#include "zg_runtime.h"
+
+using namespace zg;
+
+struct zg_layer {
+    void *c_attn_w, *c_proj_w, *c_fc_w, *mlp_proj_w;
+    float *ln_1_g, *ln_1_b, *c_attn_b, *c_proj_b, *ln_2_g, *ln_2_b, *c_fc_b, *mlp_proj_b;
+    void *k_cache, *v_cache;
+};
+
+struct zg_gpt {
+    zg_gpt_config cfg;
+    size_t batch;
+    unsigned flags;
+    int wt;        // WT_BF16 / WT_F32
+    int kv_f16;
+    size_t wbytes;  // bytes per matrix element
+    char* arena;
+    size_t arena_bytes, weight_region_bytes;
+    void *wte, *wpe;
+    float *ln_f_g, *ln_f_b;
+    std::vector<zg_layer> layers;
+    // state
+    StepCtrl* ctrl;
+    float *x, *q, *h4, *part, *logits, *part_val;
+    int *part_idx, *prompt, *prompt_len, *forced, *cur_token, *out_tokens;
+    int max_splits, lm_grid;
+    // pinned host mirrors for small control traffic
+    StepCtrl* h_ctrl;
+    int* h_ints;  // [batch * ctx] staging for prompts / tokens
+    // graphs
+    hipGraphExec_t graph[2];  // [0] without lm_head, [1] with
+    hipStream_t graph_stream;
+    size_t steps_enqueued;
+};
+
+namespace {
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        const size_t o = off;
+        off += bytes;
+        return o;
+    }
+};
+
+// One pass computes sizes (base == nullptr) or assigns pointers.
+void carve(zg_gpt* g, char* base) {
+    const zg_gpt_config& c = g->cfg;
+    const size_t E = c.n_embed, V = c.vocab_size, C = c.context_size, L = c.n_layer, B = g->batch;
+    const size_t wb = g->wbytes, kvb = g->kv_f16 ? 2 : 4;
+    Carver cv;
+    auto P = [&](size_t bytes) -> char* {
+        const size_t o = cv.take(bytes);
+        return base ? base + o : nullptr;
+    };
+    g->wte = P(V * E * wb);
+    g->wpe = P(C * E * wb);
+    g->ln_f_g = (float*)P(E * 4);
+    g->ln_f_b = (float*)P(E * 4);
+    g->layers.resize(L);
+    for (size_t l = 0; l < L; ++l) {
+        zg_layer& y = g->layers[l];
+        y.c_attn_w = P(3 * E * E * wb);
+        y.c_proj_w = P(E * E * wb);
+        y.c_fc_w = P(4 * E * E * wb);
+        y.mlp_proj_w = P(4 * E * E * wb);
+        y.ln_1_g = (float*)P(E * 4);
+        y.ln_1_b = (float*)P(E * 4);
+        y.c_attn_b = (float*)P(3 * E * 4);
+        y.c_proj_b = (float*)P(E * 4);
+        y.ln_2_g = (float*)P(E * 4);
+        y.ln_2_b = (float*)P(E * 4);
+        y.c_fc_b = (float*)P(4 * E * 4);
+        y.mlp_proj_b = (float*)P(E * 4);
+    }
+    g->weight_region_bytes = (cv.off + 255) & ~(size_t)255;
+    for (size_t l = 0; l < L; ++l) {
+        g->layers[l].k_cache = P(B * C * E * kvb);
+        g->layers[l].v_cache = P(B * C * E * kvb);
+    }
+    g->ctrl = (StepCtrl*)P(sizeof(StepCtrl));
+    g->x = (float*)P(B * E * 4);
+    g->q = (float*)P(B * E * 4);
+    g->h4 = (float*)P(B * 4 * E * 4);
+    g->part = (float*)P(B * c.n_heads * g->max_splits * kPartStride * 4);
+    g->logits = (float*)P(B * V * 4);
+    g->part_val = (float*)P(B * 4096 * 4);
+    g->part_idx = (int*)P(B * 4096 * 4);
+    g->prompt = (int*)P(B * C * 4);
+    g->prompt_len = (int*)P(B * 4);
+    g->forced = (int*)P(B * 4);
+    g->cur_token = (int*)P(B * 4);
+    g->out_tokens = (int*)P(B * C * 4);
+    g->arena_bytes = (cv.off + 255) & ~(size_t)255;
+}
+
+GemvArgs base_gemv(const zg_gpt* g, const void* W, const float* bias, size_t N, size_t K) {
+    GemvArgs a{};
+    a.W = W;
+    a.bias = bias;
+    a.N = (int)N;
+    a.K = (int)K;
+    a.M = (int)g->batch;
+    a.eps = 1e-5f;  // LayerNorm.eps default, ops.zig:76
+    a.ctrl = g->ctrl;
+    a.n_heads = (int)g->cfg.n_heads;
+    a.head_dim = 64;
+    a.max_splits = g->max_splits;
+    a.ctx = (int)g->cfg.context_size;
+    a.kv_f16 = g->kv_f16;
+    return a;
+}
+
+EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
+    EmbedArgs e{};
+    e.ctrl = g->ctrl;
+    e.wte = g->wte;
+    e.wpe = g->wpe;
+    e.weight_type = g->wt;
+    e.n_embed = (int)g->cfg.n_embed;
+    e.batch = (int)g->batch;
+    e.vocab = (int)g->cfg.vocab_size;
+    e.prompt = g->prompt;
+    e.prompt_stride = (int)g->cfg.context_size;
+    e.prompt_len = g->prompt_len;
+    e.forced = g->forced;
+    e.cur_token = g->cur_token;
+    e.out_tokens = g->out_tokens;
+    e.out_stride = (int)g->cfg.context_size;
+    e.part_val = g->part_val;
+    e.part_idx = g->part_idx;
+    e.part_stride = 4096;
+    e.x = g->x;
+    e.finish_only = finish_only;
+    return e;
+}
+
+int enqueue_lm_head(zg_gpt* g, hipStream_t s) {
+    const size_t E = g->cfg.n_embed, V = g->cfg.vocab_size;
+    // ln_f (main.zig:189) + lm_head = wte, no bias (main.zig:192-194, :312) + greedy partial argmax
+    GemvArgs a = base_gemv(g, g->wte, nullptr, V, E);
+    a.prologue = PRO_LAYERNORM;
+    a.x = g->x;
+    a.x_stride = (int)E;
+    a.ln_g = g->ln_f_g;
+    a.ln_b = g->ln_f_b;
+    a.epilogue = EPI_ARGMAX;
+    a.logits = g->logits;
+    a.logits_stride = (int)V;
+    a.part_val = g->part_val;
+    a.part_idx = g->part_idx;
+    const int grid = gemv_plan(a);
+    ZG_REQUIRE(grid == g->lm_grid, ZG_ERR_ARG, "lm_head grid changed");
+    return launch_gemv(a, g->wt, grid, s);
+}
+
+// Optional per-kernel event recorder (zg_gpt_profile_step only).
+struct StepProf {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;  // kernel class of the interval ENDING at ev[i]
+    size_t n = 0;
+};
+inline int prof_mark(StepProf* p, int cls, hipStream_t s) {
+    if (!p) return ZG_OK;
+    if (p->n == p->ev.size()) {
+        hipEvent_t e;
+        ZG_HIP(hipEventCreate(&e));
+        p->ev.push_back(e);
+        p->cls.push_back(cls);
+    }
+    p->cls[p->n] = cls;
+    ZG_HIP(hipEventRecord(p->ev[p->n++], s));
+    return ZG_OK;
+}
+
+// One decode step = GPT.forward (main.zig:178-195) for all sequences.
+int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nullptr) {
+    const size_t E = g->cfg.n_embed;
+    ZG_TRY(prof_mark(prof, -1, s));
+    ZG_TRY(launch_embed_step(embed_args(g, 0), s));  // main.zig:179-183 (+ token selection)
+    ZG_TRY(prof_mark(prof, 0, s));
+    for (size_t l = 0; l < g->cfg.n_layer; ++l) {
+        const zg_layer& y = g->layers[l];
+        {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
+            GemvArgs a = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * E, E);
+            a.prologue = PRO_LAYERNORM;
+            a.x = g->x;
+            a.x_stride = (int)E;
+            a.ln_g = y.ln_1_g;
+            a.ln_b = y.ln_1_b;
+            a.epilogue = EPI_QKV;
+            a.q = g->q;
+            a.k_cache = y.k_cache;
+            a.v_cache = y.v_cache;
+            const int grid = gemv_plan(a);
+            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(prof_mark(prof, 1, s));
+        }
+        {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
+            AttnArgs a{};
+            a.q = g->q;
+            a.k = y.k_cache;
+            a.v = y.v_cache;
+            a.stride_b = (long)(g->cfg.context_size * E);
+            a.stride_h = (long)(g->cfg.context_size * 64);
+            a.stride_t = 64;
+            a.kv_f16 = g->kv_f16;
+            a.n_heads = (int)g->cfg.n_heads;
+            a.head_dim = 64;
+            a.batch = (int)g->batch;
+            a.ctrl = g->ctrl;
+            a.max_splits = g->max_splits;
+            a.part = g->part;
+            ZG_TRY(launch_attn_decode(a, s));
+            ZG_TRY(prof_mark(prof, 2, s));
+        }
+        {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
+            GemvArgs a = base_gemv(g, y.c_proj_w, y.c_proj_b, E, E);
+            a.prologue = PRO_ATTN_MERGE;
+            a.part = g->part;
+            a.epilogue = EPI_RESIDUAL;
+            a.y = g->x;
+            a.y_stride = (int)E;
+            a.resid = g->x;
+            a.resid_stride = (int)E;
+            const int grid = gemv_plan(a);
+            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(prof_mark(prof, 3, s));
+        }
+        {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
+            GemvArgs a = base_gemv(g, y.c_fc_w, y.c_fc_b, 4 * E, E);
+            a.prologue = PRO_LAYERNORM;
+            a.x = g->x;
+            a.x_stride = (int)E;
+            a.ln_g = y.ln_2_g;
+            a.ln_b = y.ln_2_b;
+            a.epilogue = EPI_GELU;
+            a.y = g->h4;
+            a.y_stride = (int)(4 * E);
+            const int grid = gemv_plan(a);
+            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(prof_mark(prof, 4, s));
+        }
+        {   // mlp c_proj + residual: main.zig:81, :142-145
+            GemvArgs a = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, E, 4 * E);
+            a.prologue = PRO_NONE;
+            a.x = g->h4;
+            a.x_stride = (int)(4 * E);
+            a.epilogue = EPI_RESIDUAL;
+            a.y = g->x;
+            a.y_stride = (int)E;
+            a.resid = g->x;
+            a.resid_stride = (int)E;
+            const int grid = gemv_plan(a);
+            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(prof_mark(prof, 5, s));
+        }
+    }
+    if (with_logits) {
+        ZG_TRY(enqueue_lm_head(g, s));
+        ZG_TRY(prof_mark(prof, 6, s));
+    }
+    return ZG_OK;
+}
+
+int ensure_graphs(zg_gpt* g, hipStream_t s) {
+    if (g->flags & ZG_GPT_NO_GRAPH) return ZG_OK;
+    if (g->graph[0] && g->graph_stream == s) return ZG_OK;
+    if (s == nullptr) return ZG_OK;  // the legacy default stream cannot be captured: stay eager
+    for (int i = 0; i < 2; ++i)
+        if (g->graph[i]) {
+            (void)hipGraphExecDestroy(g->graph[i]);
+            g->graph[i] = nullptr;
+        }
+    for (int i = 0; i < 2; ++i) {
+        hipGraph_t graph = nullptr;
+        ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int st = enqueue_step(g, i == 1, s);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (st != ZG_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return st;
+        }
+        ZG_HIP(e);
+        ZG_HIP(hipGraphInstantiate(&g->graph[i], graph, nullptr, nullptr, 0));
+        ZG_HIP(hipGraphDestroy(graph));
+    }
+    g->graph_stream = s;
+    return ZG_OK;
+}
+
+int run_step(zg_gpt* g, bool with_logits, hipStream_t s) {
+    if (g->graph[0] && g->graph_stream == s) {
+        ZG_HIP(hipGraphLaunch(g->graph[with_logits ? 1 : 0], s));
+        return ZG_OK;
+    }
+    return enqueue_step(g, with_logits, s);
+}
+
+int upload_f32(const float* src, size_t n, void* dst, bool as_bf16, hipStream_t s) {
+    // src may be host or device; matrices are converted on the device.
+    Ctx& c = ctx();
+    const float* dsrc = src;
+    if (!is_device_ptr(src)) {
+        if (!as_bf16) {
+            ZG_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyHostToDevice, s));
+            ZG_HIP(hipStreamSynchronize(s));
+            return ZG_OK;
+        }
+        // chunk through the staging arena
+        const size_t cap = c.stage_cap / 4;
+        ZG_REQUIRE(cap > 0, ZG_ERR_STAGING, "no staging arena");
+        for (size_t o = 0; o < n; o += cap) {
+            const size_t m = (n - o < cap) ? (n - o) : cap;
+            ZG_HIP(hipMemcpyAsync(c.stage, src + o, m * 4, hipMemcpyHostToDevice, s));
+            ZG_TRY(launch_f32_to_bf16(reinterpret_cast<const float*>(c.stage), reinterpret_cast<bf16_t*>(dst) + o, m, s));
+            ZG_HIP(hipStreamSynchronize(s));
+        }
+        return ZG_OK;
+    }
+    if (as_bf16) ZG_TRY(launch_f32_to_bf16(dsrc, reinterpret_cast<bf16_t*>(dst), n, s));
+    else ZG_HIP(hipMemcpyAsync(dst, dsrc, n * 4, hipMemcpyDeviceToDevice, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsigned flags) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(out && config, ZG_ERR_ARG, "zg_gpt_create: null argument");
+    const zg_gpt_config& c = *config;
+    ZG_REQUIRE(c.n_heads > 0 && c.n_embed % c.n_heads == 0 && c.n_embed / c.n_heads == 64, ZG_ERR_UNSUPPORTED,
+               "head_dim %zu != 64 (GPT-2 family only)", c.n_heads ? c.n_embed / c.n_heads : (size_t)0);
+    ZG_REQUIRE(c.n_embed % 8 == 0 && c.n_embed * 4 <= 8192, ZG_ERR_UNSUPPORTED, "n_embed %zu unsupported", c.n_embed);
+    ZG_REQUIRE(batch >= 1 && batch <= 8, ZG_ERR_UNSUPPORTED, "batch %zu outside 1..8", batch);
+    ZG_REQUIRE(c.vocab_size > 0 && c.context_size > 0 && c.n_layer > 0, ZG_ERR_ARG, "empty config");
+    zg_gpt* g = new zg_gpt();
+    g->cfg = c;
+    g->batch = batch;
+    g->flags = flags;
+    g->wt = (flags & ZG_GPT_WEIGHTS_F32) ? WT_F32 : WT_BF16;
+    g->wbytes = g->wt == WT_BF16 ? 2 : 4;
+    g->kv_f16 = (flags & ZG_GPT_KV_F16) ? 1 : 0;
+    g->max_splits = (int)((c.context_size + kAttnChunk - 1) / kAttnChunk);
+    g->graph[0] = g->graph[1] = nullptr;
+    g->graph_stream = nullptr;
+    carve(g, nullptr);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->arena), g->arena_bytes);
+    if (e != hipSuccess) {
+        delete g;
+        return hip_fail(e, "hipMalloc(model arena)", __FILE__, __LINE__);
+    }
+    carve(g, g->arena);
+    (void)hipMemset(g->arena + g->weight_region_bytes, 0, g->arena_bytes - g->weight_region_bytes);
+    {
+        GemvArgs a = base_gemv(g, g->wte, nullptr, c.vocab_size, c.n_embed);
+        g->lm_grid = gemv_plan(a);
+    }
+    if (g->lm_grid > 4096) {
+        (void)hipFree(g->arena);
+        delete g;
+        set_error("lm_head grid %d exceeds the argmax partial buffer", g->lm_grid);
+        return ZG_ERR_UNSUPPORTED;
+    }
+    (void)hipHostMalloc(reinterpret_cast<void**>(&g->h_ctrl), sizeof(StepCtrl), hipHostMallocDefault);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&g->h_ints), (batch * c.context_size + batch) * sizeof(int),
+                        hipHostMallocDefault);
+    g->steps_enqueued = 0;
+    *out = g;
+    return ZG_OK;
+}
+
+int zg_gpt_destroy(zg_gpt* g) {
+    if (!g) return ZG_OK;
+    (void)hipStreamSynchronize(ctx().stream);
+    for (int i = 0; i < 2; ++i)
+        if (g->graph[i]) (void)hipGraphExecDestroy(g->graph[i]);
+    (void)hipFree(g->arena);
+    (void)hipHostFree(g->h_ctrl);
+    (void)hipHostFree(g->h_ints);
+    delete g;
+    return ZG_OK;
+}
+
+int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src, size_t len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && src && layer < g->cfg.n_layer, ZG_ERR_ARG, "load_block_tensor: bad argument");
+    const size_t E = g->cfg.n_embed;
+    zg_layer& y = g->layers[layer];
+    void* dst = nullptr;
+    size_t n = 0;
+    bool mat = false;
+    switch (slot) {
+        case ZG_LN_1_G: dst = y.ln_1_g; n = E; break;
+        case ZG_LN_1_B: dst = y.ln_1_b; n = E; break;
+        case ZG_C_ATTN_W: dst = y.c_attn_w; n = 3 * E * E; mat = true; break;
+        case ZG_C_ATTN_B: dst = y.c_attn_b; n = 3 * E; break;
+        case ZG_C_PROJ_W: dst = y.c_proj_w; n = E * E; mat = true; break;
+        case ZG_C_PROJ_B: dst = y.c_proj_b; n = E; break;
+        case ZG_LN_2_G: dst = y.ln_2_g; n = E; break;
+        case ZG_LN_2_B: dst = y.ln_2_b; n = E; break;
+        case ZG_C_FC_W: dst = y.c_fc_w; n = 4 * E * E; mat = true; break;
+        case ZG_C_FC_B: dst = y.c_fc_b; n = 4 * E; break;
+        case ZG_MLP_PROJ_W: dst = y.mlp_proj_w; n = 4 * E * E; mat = true; break;
+        case ZG_MLP_PROJ_B: dst = y.mlp_proj_b; n = E; break;
+        default: ZG_REQUIRE(false, ZG_ERR_ARG, "unknown block slot %d", slot);
+    }
+    ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "block slot %d expects %zu elements, got %zu", slot, n, len);
+    return upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream);
+}
+
+int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && src, ZG_ERR_ARG, "load_tensor: bad argument");
+    const size_t E = g->cfg.n_embed;
+    void* dst = nullptr;
+    size_t n = 0;
+    bool mat = false;
+    switch (slot) {
+        case ZG_WTE: dst = g->wte; n = g->cfg.vocab_size * E; mat = true; break;
+        case ZG_WPE: dst = g->wpe; n = g->cfg.context_size * E; mat = true; break;
+        case ZG_LN_F_G: dst = g->ln_f_g; n = E; break;
+        case ZG_LN_F_B: dst = g->ln_f_b; n = E; break;
+        default: ZG_REQUIRE(false, ZG_ERR_ARG, "unknown slot %d", slot);
+    }
+    ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "slot %d expects %zu elements, got %zu", slot, n, len);
+    return upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream);
+}
+
+int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes) {
+    ZG_REQUIRE(g && device_ptr && bytes, ZG_ERR_ARG, "weight_arena: null argument");
+    *device_ptr = g->arena;
+    *bytes = g->weight_region_bytes;
+    return ZG_OK;
+}
+
+int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* kv_bytes) {
+    ZG_REQUIRE(g, ZG_ERR_ARG, "step_bytes: null argument");
+    const size_t E = g->cfg.n_embed;
+    // wbytes * (sum_layers in*out + V*E) + kvbytes * 2 * T * E * L (per sequence)
+    if (weight_bytes) *weight_bytes = g->wbytes * (g->cfg.n_layer * 12 * E * E + g->cfg.vocab_size * E);
+    if (kv_bytes) *kv_bytes = (g->kv_f16 ? 2 : 4) * 2 * seq_len * E * g->cfg.n_layer * g->batch;
+    return ZG_OK;
+}
+
+int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens, int compute_logits,
+                   float* logits_out, size_t logits_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && tokens, ZG_ERR_ARG, "gpt_forward: null argument");
+    ZG_REQUIRE(n_tokens == g->batch, ZG_ERR_SHAPE, "gpt_forward: %zu tokens for batch %zu", n_tokens, g->batch);
+    ZG_REQUIRE(seq_len >= 1 && seq_len <= g->cfg.context_size, ZG_ERR_SHAPE, "gpt_forward: seq_len %zu outside 1..%zu",
+               seq_len, g->cfg.context_size);
+    const size_t V = g->cfg.vocab_size;
+    ZG_REQUIRE(!logits_out || (compute_logits && logits_len >= g->batch * V), ZG_ERR_SHAPE,
+               "gpt_forward: logits_out needs compute_logits and %zu elements", g->batch * V);
+    hipStream_t s = ctx().stream;
+    for (size_t b = 0; b < g->batch; ++b) {
+        ZG_REQUIRE(tokens[b] < V, ZG_ERR_SHAPE, "gpt_forward: token %zu >= vocab %zu", tokens[b], V);
+        g->h_ints[b] = (int)tokens[b];
+    }
+    ZG_TRY(ensure_graphs(g, s));
+    g->h_ctrl->step = (int)seq_len - 1;
+    g->h_ctrl->seq_len = (int)seq_len;
+    g->h_ctrl->mode = 1;
+    g->h_ctrl->n_partials = g->lm_grid;
+    ZG_HIP(hipMemcpyAsync(g->forced, g->h_ints, g->batch * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    ZG_TRY(run_step(g, compute_logits != 0, s));
+    if (logits_out) {
+        ZG_HIP(hipMemcpyAsync(logits_out, g->logits, g->batch * V * sizeof(float),
+                              is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    }
+    // h_ints / h_ctrl are reused by the next call: drain before returning.
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+
+int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && tokens_out && n_tokens == g->batch, ZG_ERR_ARG, "gpt_argmax: bad argument");
+    hipStream_t s = ctx().stream;
+    ZG_TRY(launch_embed_step(embed_args(g, 2), s));
+    ZG_HIP(hipMemcpyAsync(g->h_ints, g->cur_token, g->batch * sizeof(int), hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < g->batch; ++b) tokens_out[b] = (size_t)g->h_ints[b];
+    return ZG_OK;
+}
+
+int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && x_out && len >= g->batch * g->cfg.n_embed, ZG_ERR_ARG, "gpt_hidden: bad argument");
+    hipStream_t s = ctx().stream;
+    ZG_HIP(hipMemcpyAsync(x_out, g->x, g->batch * g->cfg.n_embed * sizeof(float),
+                          is_device_ptr(x_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+
+int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens,
+                            size_t n_steps) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && prompts && prompt_lens, ZG_ERR_ARG, "generate: null argument");
+    const size_t C = g->cfg.context_size, V = g->cfg.vocab_size, B = g->batch;
+    ZG_REQUIRE(n_steps >= 1 && n_steps <= C, ZG_ERR_SHAPE, "generate: n_steps %zu outside 1..%zu", n_steps, C);
+    hipStream_t s = ctx().stream;
+    ZG_HIP(hipStreamSynchronize(s));  // pinned staging below is shared with earlier calls
+    size_t min_prompt = C;
+    memset(g->h_ints, 0, (B * C + B) * sizeof(int));
+    for (size_t b = 0; b < B; ++b) {
+        const size_t np = prompt_lens[b];
+        ZG_REQUIRE(np >= 1 && np <= C && np <= prompt_stride, ZG_ERR_SHAPE, "generate: prompt %zu has length %zu", b, np);
+        for (size_t i = 0; i < np; ++i) {
+            const size_t t = prompts[b * prompt_stride + i];
+            ZG_REQUIRE(t < V, ZG_ERR_SHAPE, "generate: token %zu >= vocab %zu", t, V);
+            g->h_ints[b * C + i] = (int)t;
+        }
+        g->h_ints[B * C + b] = (int)np;
+        if (np < min_prompt) min_prompt = np;
+    }
+    ZG_TRY(ensure_graphs(g, s));
+    g->h_ctrl->step = 0;
+    g->h_ctrl->seq_len = 0;
+    g->h_ctrl->mode = 0;
+    g->h_ctrl->n_partials = g->lm_grid;
+    ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    for (size_t st = 0; st < n_steps; ++st) ZG_TRY(run_step(g, st >= min_prompt, s));  // main.zig:330-338
+    ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
+    g->steps_enqueued = n_steps;
+    return ZG_OK;
+}
+
+int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t out_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && out_tokens, ZG_ERR_ARG, "generate_fetch: null argument");
+    const size_t C = g->cfg.context_size, B = g->batch;
+    ZG_REQUIRE(n_steps <= C && out_len >= B * n_steps, ZG_ERR_SHAPE, "generate_fetch: out_tokens too short");
+    hipStream_t s = ctx().stream;
+    ZG_HIP(hipMemcpyAsync(g->h_ints, g->out_tokens, B * C * sizeof(int), hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; ++b)
+        for (size_t i = 0; i < n_steps; ++i) out_tokens[b * n_steps + i] = (size_t)g->h_ints[b * C + i];
+    return ZG_OK;
+}
+
+int zg_gpt_generate_greedy(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens,
+                           size_t n_steps, size_t* out_tokens, size_t out_len) {
+    ZG_REQUIRE(g && out_tokens && out_len >= g->batch * n_steps, ZG_ERR_SHAPE, "generate: out_tokens too short");
+    ZG_TRY(zg_gpt_generate_enqueue(g, prompts, prompt_stride, prompt_lens, n_steps));
+    return zg_gpt_generate_fetch(g, n_steps, out_tokens, out_len);
+}
+
+int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, size_t n_out) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && us_out && n_out >= 8 && iters > 0, ZG_ERR_ARG, "profile_step: bad argument");
+    ZG_REQUIRE(seq_len >= 1 && seq_len + (size_t)iters - 1 <= g->cfg.context_size, ZG_ERR_SHAPE,
+               "profile_step: positions %zu..%zu outside the context", seq_len, seq_len + iters - 1);
+    hipStream_t s = ctx().stream;
+    ZG_HIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < g->batch; ++b) g->h_ints[b] = (int)(b % g->cfg.vocab_size);
+    g->h_ctrl->step = (int)seq_len - 1;
+    g->h_ctrl->seq_len = (int)seq_len;
+    g->h_ctrl->mode = 1;
+    g->h_ctrl->n_partials = g->lm_grid;
+    ZG_HIP(hipMemcpyAsync(g->forced, g->h_ints, g->batch * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    static StepProf prof;  // events are created on first use and reused
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        prof.n = 0;
+        ZG_TRY(enqueue_step(g, true, s, &prof));  // eager launches; the embed kernel advances the position
+        ZG_HIP(hipStreamSynchronize(s));
+        for (size_t i = 1; i < prof.n; ++i) {
+            float ms = 0.0f;
+            ZG_HIP(hipEventElapsedTime(&ms, prof.ev[i - 1], prof.ev[i]));
+            acc[prof.cls[i]] += ms * 1000.0;
+            acc[7] += ms * 1000.0;
+        }
+    }
+    for (int i = 0; i < 8; ++i) us_out[i] = (float)(acc[i] / iters);
+    return ZG_OK;
+}
+
+int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && avg_us && iters > 0, ZG_ERR_ARG, "time_kernel: bad argument");
+    hipStream_t s = ctx().stream;
+    hipEvent_t e0, e1;
+    ZG_HIP(hipEventCreate(&e0));
+    ZG_HIP(hipEventCreate(&e1));
+    const size_t E = g->cfg.n_embed;
+    size_t bytes = 0;
+    int st = ZG_OK;
+    ZG_HIP(hipStreamSynchronize(s));
+    ZG_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters && st == ZG_OK; ++i) {
+        switch (which) {
+            case ZG_TIME_LM_HEAD:
+                st = enqueue_lm_head(g, s);
+                bytes = g->cfg.vocab_size * E * g->wbytes;
+                break;
+            default:
+                set_error("time_kernel: unknown kernel %d", which);
+                st = ZG_ERR_ARG;
+        }
+    }
+    ZG_HIP(hipEventRecord(e1, s));
+    ZG_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    ZG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = ms * 1000.0f / (float)iters;
+    if (algorithmic_bytes) *algorithmic_bytes = bytes;
+    return st;
+}
+
+}  // extern "C"

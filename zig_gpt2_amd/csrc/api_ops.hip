@@ -1,0 +1,491 @@
+// api_ops.hip — runtime + op tier of the C ABI (include/zgpt2.h): one entry point per public decl
+// of the reference's src/ops.zig, same argument meaning, Zig slices passed as (ptr, len).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "zg_runtime.h"
+
+namespace zg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    return ZG_ERR_HIP;
+}
+
+Ctx& ctx() {
+    static Ctx c;
+    return c;
+}
+
+int require_init() {
+    ZG_REQUIRE(ctx().inited, ZG_ERR_NOT_INITIALIZED, "zg_init has not been called");
+    return ZG_OK;
+}
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// ------------------------------------------------------------------------------------- Call
+Call::Call() : mark_(ctx().stage_off), s_(ctx().stream) {}
+
+int Call::alloc(size_t bytes, void** dev) {
+    Ctx& c = ctx();
+    const size_t off = (c.stage_off + 255) & ~(size_t)255;
+    ZG_REQUIRE(off + bytes <= c.stage_cap, ZG_ERR_STAGING,
+               "host buffers of this call need %zu more bytes than the %zu-byte staging arena "
+               "(raise ZGPT2_STAGING_MB / zg_init_ex, pass device pointers, or zg_register_tensor the weights)",
+               off + bytes - c.stage_cap, c.stage_cap);
+    *dev = c.stage + off;
+    c.stage_off = off + bytes;
+    return ZG_OK;
+}
+
+int Call::stage_in(const void* p, size_t bytes, const void** dev) {
+    if (bytes == 0 || p == nullptr) {
+        *dev = p;
+        return ZG_OK;
+    }
+    if (is_device_ptr(p)) {
+        *dev = p;
+        return ZG_OK;
+    }
+    auto it = ctx().registry.find(p);
+    if (it != ctx().registry.end() && it->second.bytes >= bytes) {
+        *dev = it->second.dev;
+        return ZG_OK;
+    }
+    void* d = nullptr;
+    ZG_TRY(alloc(bytes, &d));
+    ZG_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, s_));
+    *dev = d;
+    return ZG_OK;
+}
+
+int Call::stage_out(void* p, size_t bytes, bool copy_in, void** dev) {
+    if (bytes == 0 || p == nullptr) {
+        *dev = p;
+        return ZG_OK;
+    }
+    if (is_device_ptr(p)) {
+        *dev = p;
+        return ZG_OK;
+    }
+    ZG_REQUIRE(n_outs_ < 16, ZG_ERR_STAGING, "too many staged outputs");
+    void* d = nullptr;
+    ZG_TRY(alloc(bytes, &d));
+    if (copy_in) ZG_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, s_));
+    outs_[n_outs_++] = Out{p, d, bytes};
+    *dev = d;
+    return ZG_OK;
+}
+
+int Call::finish() {
+    for (int i = 0; i < n_outs_; ++i)
+        ZG_HIP(hipMemcpyAsync(outs_[i].host, outs_[i].dev, outs_[i].bytes, hipMemcpyDeviceToHost, s_));
+    // Op-tier calls are synchronous on return: the reference's host code reads the buffers next.
+    ZG_HIP(hipStreamSynchronize(s_));
+    ctx().stage_off = mark_;
+    n_outs_ = 0;
+    return ZG_OK;
+}
+
+// A failed call must still release the arena.
+struct CallGuard {
+    Call& c;
+    bool done = false;
+    explicit CallGuard(Call& cc) : c(cc) {}
+    ~CallGuard() {
+        if (!done) {
+            (void)hipStreamSynchronize(c.stream());
+            ctx().stage_off = 0;
+        }
+    }
+};
+
+static int linear_device(size_t in_f, size_t out_f, const float* w, const float* bias, const float* x,
+                         size_t m, float* y, hipStream_t s) {
+    if (m == 0 || out_f == 0) return ZG_OK;
+    ZG_REQUIRE(in_f > 0 && in_f <= 8192, ZG_ERR_UNSUPPORTED, "Linear: in_features %zu outside 1..8192", in_f);
+    size_t mb = 8;
+    while (mb > 1 && mb * in_f * sizeof(float) > 160 * 1024) mb >>= 1;
+    for (size_t m0 = 0; m0 < m; m0 += mb) {
+        GemvArgs a{};
+        a.W = w;
+        a.bias = bias;
+        a.N = (int)out_f;
+        a.K = (int)in_f;
+        a.M = (int)((m - m0 < mb) ? (m - m0) : mb);
+        a.prologue = PRO_NONE;
+        a.epilogue = EPI_STORE;
+        a.x = x + m0 * in_f;
+        a.x_stride = (int)in_f;
+        a.y = y + m0 * out_f;
+        a.y_stride = (int)out_f;
+        const int grid = gemv_plan(a);
+        ZG_TRY(launch_gemv(a, WT_F32, grid, s));
+    }
+    return ZG_OK;
+}
+
+static int attn_core(const float* q, const float* k, const float* v, long stride_b, long stride_h,
+                     long stride_t, size_t batch, size_t n_heads, size_t seq_len, float* out, hipStream_t s) {
+    Ctx& c = ctx();
+    const int splits = (int)((seq_len + kAttnChunk - 1) / kAttnChunk);
+    ZG_REQUIRE(batch * n_heads * splits * kPartStride <= c.attn_part_floats, ZG_ERR_UNSUPPORTED,
+               "attention: batch*heads*splits = %zu exceeds the op-tier partial buffer", batch * n_heads * splits);
+    AttnArgs a{};
+    a.q = q;
+    a.k = k;
+    a.v = v;
+    a.stride_b = stride_b;
+    a.stride_h = stride_h;
+    a.stride_t = stride_t;
+    a.n_heads = (int)n_heads;
+    a.head_dim = 64;
+    a.batch = (int)batch;
+    a.ctrl = nullptr;
+    a.seq_len = (int)seq_len;
+    a.max_splits = splits;
+    a.part = c.attn_part;
+    ZG_TRY(launch_attn_decode(a, s));
+    return launch_attn_merge(c.attn_part, (int)batch, (int)n_heads, 64, splits, (int)seq_len, out, s);
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+const char* zg_last_error(void) { return zg::g_err; }
+
+int zg_init_ex(int device, size_t staging_bytes) {
+    Ctx& c = ctx();
+    if (c.inited) {
+        ZG_REQUIRE(c.device == device, ZG_ERR_ARG, "already initialised on device %d", c.device);
+        return ZG_OK;
+    }
+    int n = 0;
+    ZG_HIP(hipGetDeviceCount(&n));
+    ZG_REQUIRE(device >= 0 && device < n, ZG_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    ZG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ZG_HIP(hipGetDeviceProperties(&prop, device));
+    ZG_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, ZG_ERR_UNSUPPORTED,
+               "libzgpt2_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    ZG_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    c.stage_cap = staging_bytes;
+    ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.stage), c.stage_cap));
+    ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_flag), sizeof(int)));
+    ZG_HIP(hipMemset(c.d_flag, 0, sizeof(int)));
+    c.attn_part_floats = (size_t)4 << 20;
+    ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.attn_part), c.attn_part_floats * sizeof(float)));
+    c.stage_off = 0;
+    c.device = device;
+    c.inited = true;
+    return ZG_OK;
+}
+
+int zg_init(int device) {
+    size_t mb = 512;
+    if (const char* e = getenv("ZGPT2_STAGING_MB")) {
+        const long v = atol(e);
+        if (v > 0) mb = (size_t)v;
+    }
+    return zg_init_ex(device, mb << 20);
+}
+
+int zg_shutdown(void) {
+    Ctx& c = ctx();
+    if (!c.inited) return ZG_OK;
+    (void)hipStreamSynchronize(c.stream);
+    for (auto& kv : c.registry) (void)hipFree(kv.second.dev);
+    c.registry.clear();
+    (void)hipFree(c.stage);
+    (void)hipFree(c.d_flag);
+    (void)hipFree(c.attn_part);
+    (void)hipStreamDestroy(c.own_stream);
+    c = Ctx();
+    return ZG_OK;
+}
+
+int zg_set_stream(void* hip_stream) {
+    ZG_TRY(require_init());
+    Ctx& c = ctx();
+    ZG_HIP(hipStreamSynchronize(c.stream));
+    c.stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c.own_stream;
+    return ZG_OK;
+}
+
+int zg_synchronize(void) {
+    ZG_TRY(require_init());
+    ZG_HIP(hipStreamSynchronize(ctx().stream));
+    return ZG_OK;
+}
+
+int zg_register_tensor(const float* host_ptr, size_t len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(host_ptr && len, ZG_ERR_ARG, "zg_register_tensor: null/empty tensor");
+    Ctx& c = ctx();
+    if (is_device_ptr(host_ptr)) return ZG_OK;
+    auto it = c.registry.find(host_ptr);
+    if (it != c.registry.end()) {
+        (void)hipFree(it->second.dev);
+        c.registry.erase(it);
+    }
+    void* d = nullptr;
+    ZG_HIP(hipMalloc(&d, len * sizeof(float)));
+    ZG_HIP(hipMemcpy(d, host_ptr, len * sizeof(float), hipMemcpyHostToDevice));
+    c.registry[host_ptr] = Registered{d, len * sizeof(float)};
+    return ZG_OK;
+}
+
+int zg_unregister_all(void) {
+    ZG_TRY(require_init());
+    Ctx& c = ctx();
+    ZG_HIP(hipStreamSynchronize(c.stream));
+    for (auto& kv : c.registry) (void)hipFree(kv.second.dev);
+    c.registry.clear();
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ Linear
+int zg_linear_forward(size_t in_features, size_t out_features, const float* weight,
+                      const float* bias_or_null, const float* inputs, size_t inputs_len,
+                      float* outputs, size_t outputs_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(in_features > 0 && weight && (inputs || inputs_len == 0), ZG_ERR_ARG, "Linear: null argument");
+    const size_t batch = inputs_len / in_features;  // ops.zig:22
+    ZG_REQUIRE(inputs_len == batch * in_features, ZG_ERR_SHAPE,
+               "Linear: inputs.len %zu is not a multiple of in_features %zu", inputs_len, in_features);
+    ZG_REQUIRE(outputs_len >= batch * out_features, ZG_ERR_SHAPE,
+               "Linear: outputs.len %zu < batch %zu * out_features %zu", outputs_len, batch, out_features);
+    Call call;
+    CallGuard guard(call);
+    const float *w, *b, *x;
+    float* y;
+    ZG_TRY(call.in(weight, in_features * out_features, &w));
+    ZG_TRY(call.in(bias_or_null, out_features, &b));
+    ZG_TRY(call.in(inputs, inputs_len, &x));
+    ZG_TRY(call.out(outputs, batch * out_features, &y));
+    ZG_TRY(linear_device(in_features, out_features, w, b, x, batch, y, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ Embedding
+int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len, const size_t* idxs,
+                         size_t idxs_len, float* embeddings, size_t embeddings_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(emb_dim > 0 && weight && (idxs || idxs_len == 0), ZG_ERR_ARG, "Embedding: null argument");
+    ZG_REQUIRE(embeddings_len >= idxs_len * emb_dim, ZG_ERR_SHAPE,
+               "Embedding: embeddings.len %zu < %zu indices * emb_dim %zu", embeddings_len, idxs_len, emb_dim);
+    Call call;
+    CallGuard guard(call);
+    const float* w;
+    const size_t* ix;
+    float* out;
+    ZG_TRY(call.in(weight, weight_len, &w));
+    ZG_TRY(call.in(idxs, idxs_len, &ix));
+    ZG_TRY(call.out(embeddings, idxs_len * emb_dim, &out));
+    ZG_TRY(launch_embedding(w, emb_dim, ix, idxs_len, weight_len / emb_dim, out, ctx().d_flag, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+int zg_layernorm_forward(size_t n_features, const float* weight, const float* bias, float eps,
+                         float* inputs, size_t inputs_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(n_features > 0 && weight && bias && (inputs || inputs_len == 0), ZG_ERR_ARG, "LayerNorm: null argument");
+    const size_t rows = inputs_len / n_features;
+    ZG_REQUIRE(inputs_len == rows * n_features, ZG_ERR_SHAPE,
+               "LayerNorm: inputs.len %zu is not a multiple of n_features %zu", inputs_len, n_features);
+    Call call;
+    CallGuard guard(call);
+    const float *g, *b;
+    float* x;
+    ZG_TRY(call.in(weight, n_features, &g));
+    ZG_TRY(call.in(bias, n_features, &b));
+    ZG_TRY(call.inout(inputs, inputs_len, &x));
+    ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ gelu / softmax
+int zg_gelu(float* inputs, size_t inputs_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(inputs || inputs_len == 0, ZG_ERR_ARG, "gelu: null argument");
+    Call call;
+    CallGuard guard(call);
+    float* x;
+    ZG_TRY(call.inout(inputs, inputs_len, &x));
+    ZG_TRY(launch_gelu(x, inputs_len, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+int zg_softmax(float* inputs, size_t inputs_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(inputs || inputs_len == 0, ZG_ERR_ARG, "softmax: null argument");
+    Call call;
+    CallGuard guard(call);
+    float* x;
+    ZG_TRY(call.inout(inputs, inputs_len, &x));
+    ZG_TRY(launch_softmax(x, inputs_len, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ split / transpose
+int zg_split_qkv(size_t n_embed, size_t seq_len, const float* inputs, size_t inputs_len,
+                 size_t split_idx, float* outputs, size_t outputs_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(n_embed > 0 && seq_len > 0 && split_idx < 3, ZG_ERR_ARG, "split_qkv: bad argument");
+    const size_t batch = inputs_len / (seq_len * 3 * n_embed);  // ops.zig:185
+    const size_t rows = batch * seq_len;
+    ZG_REQUIRE(outputs_len >= rows * n_embed, ZG_ERR_SHAPE, "split_qkv: outputs.len %zu < %zu", outputs_len,
+               rows * n_embed);
+    Call call;
+    CallGuard guard(call);
+    const float* in;
+    float* out;
+    ZG_TRY(call.in(inputs, inputs_len, &in));
+    ZG_TRY(call.out(outputs, rows * n_embed, &out));
+    ZG_TRY(launch_split_qkv(in, rows, n_embed, split_idx, out, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+int zg_transpose(size_t seq_len, size_t n_heads, size_t head_dim, const float* inputs,
+                 size_t inputs_len, float* outputs, size_t outputs_len) {
+    ZG_TRY(require_init());
+    const size_t per = seq_len * n_heads * head_dim;
+    ZG_REQUIRE(per > 0, ZG_ERR_ARG, "transpose: empty shape");
+    const size_t batch = inputs_len / per;  // ops.zig:203
+    ZG_REQUIRE(outputs_len >= batch * per, ZG_ERR_SHAPE, "transpose: outputs.len %zu < %zu", outputs_len, batch * per);
+    ZG_REQUIRE(n_heads <= 65535 && batch <= 65535, ZG_ERR_UNSUPPORTED, "transpose: n_heads/batch > 65535");
+    Call call;
+    CallGuard guard(call);
+    const float* in;
+    float* out;
+    ZG_TRY(call.in(inputs, inputs_len, &in));
+    ZG_TRY(call.out(outputs, batch * per, &out));
+    ZG_TRY(launch_transpose(in, batch, seq_len, n_heads, head_dim, out, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ sdpa
+int zg_scaled_dot_product_attention(const float* q, size_t q_len, const float* k, size_t k_len,
+                                    const float* v, size_t v_len, size_t n_heads, size_t seq_len,
+                                    size_t head_dim, float* outputs, size_t outputs_len, float* _attn,
+                                    size_t _attn_len) {
+    ZG_TRY(require_init());
+    (void)_attn;
+    ZG_REQUIRE(n_heads > 0 && seq_len > 0 && head_dim > 0, ZG_ERR_ARG, "sdpa: empty shape");
+    ZG_REQUIRE(head_dim == 64, ZG_ERR_UNSUPPORTED, "sdpa: head_dim %zu != 64 (GPT-2 family only)", head_dim);
+    const size_t batch = k_len / (n_heads * seq_len * head_dim);  // ops.zig:259
+    ZG_REQUIRE(v_len >= k_len && q_len >= batch * n_heads * head_dim && outputs_len >= batch * n_heads * head_dim &&
+                   _attn_len >= seq_len,
+               ZG_ERR_SHAPE, "sdpa: slice lengths inconsistent with batch %zu", batch);
+    Call call;
+    CallGuard guard(call);
+    const float *dq, *dk, *dv;
+    float* out;
+    ZG_TRY(call.in(q, batch * n_heads * head_dim, &dq));
+    ZG_TRY(call.in(k, k_len, &dk));
+    ZG_TRY(call.in(v, k_len, &dv));
+    ZG_TRY(call.out(outputs, batch * n_heads * head_dim, &out));
+    ZG_TRY(attn_core(dq, dk, dv, (long)(n_heads * seq_len * head_dim), (long)(seq_len * head_dim), (long)head_dim,
+                     batch, n_heads, seq_len, out, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------ CausalSelfAttention
+int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, const float* c_attn_bias,
+                    const float* c_proj_weight, const float* c_proj_bias, size_t seq_len,
+                    const float* inputs, size_t inputs_len, float* k_cache, size_t k_cache_len,
+                    float* v_cache, size_t v_cache_len, float* outputs, size_t outputs_len, float* _qkv,
+                    size_t _qkv_len, float* _q, size_t _q_len, float* _k, size_t _k_len, float* _v,
+                    size_t _v_len, float* _attn, size_t _attn_len) {
+    ZG_TRY(require_init());
+    (void)_k;
+    (void)_v;
+    (void)_attn;
+    const size_t E = n_embed;
+    ZG_REQUIRE(n_heads > 0 && E > 0 && seq_len > 0, ZG_ERR_ARG, "attn: empty shape");
+    ZG_REQUIRE(E % n_heads == 0 && E / n_heads == 64, ZG_ERR_UNSUPPORTED,
+               "attn: head_dim %zu != 64 (GPT-2 family only)", E / n_heads);
+    ZG_REQUIRE(inputs_len == E, ZG_ERR_SHAPE, "attn: batch must be 1 (inputs.len %zu != n_embed %zu; ops.zig:126-128)",
+               inputs_len, E);
+    ZG_REQUIRE(k_cache_len >= seq_len * E && v_cache_len >= seq_len * E && outputs_len >= E &&
+                   _qkv_len >= 3 * E && _q_len >= E && _k_len >= seq_len * E && _v_len >= seq_len * E &&
+                   _attn_len >= seq_len,
+               ZG_ERR_SHAPE, "attn: a slice is shorter than seq_len %zu * n_embed %zu requires", seq_len, E);
+    Call call;
+    CallGuard guard(call);
+    hipStream_t s = call.stream();
+    const float *caw, *cab, *cpw, *cpb, *x;
+    float *kc, *vc, *out, *qkv, *q;
+    ZG_TRY(call.in(c_attn_weight, 3 * E * E, &caw));
+    ZG_TRY(call.in(c_attn_bias, 3 * E, &cab));
+    ZG_TRY(call.in(c_proj_weight, E * E, &cpw));
+    ZG_TRY(call.in(c_proj_bias, E, &cpb));
+    ZG_TRY(call.in(inputs, E, &x));
+    // Host caches: rows 0..T-2 go up, row T-1 comes back (the caller owns the cache, ops.zig:152,157).
+    const bool k_host = !is_device_ptr(k_cache), v_host = !is_device_ptr(v_cache);
+    ZG_TRY(call.inout(k_cache, seq_len * E, &kc));
+    ZG_TRY(call.inout(v_cache, seq_len * E, &vc));
+    ZG_TRY(call.out(outputs, E, &out));
+    ZG_TRY(call.out(_qkv, 3 * E, &qkv));
+    ZG_TRY(call.out(_q, E, &q));
+    (void)k_host;
+    (void)v_host;
+    // c_attn (ops.zig:143)
+    ZG_TRY(linear_device(E, 3 * E, caw, cab, x, 1, qkv, s));
+    // cache append (ops.zig:151-152, :156-157)
+    ZG_TRY(launch_copy_f32(qkv + E, kc + (seq_len - 1) * E, E, s));
+    ZG_TRY(launch_copy_f32(qkv + 2 * E, vc + (seq_len - 1) * E, E, s));
+    // attention straight over the [T, H, hd] cache (replaces transposes + sdpa, ops.zig:153-171);
+    // the merged heads land in _q like the reference's "untranspose" (ops.zig:171)
+    ZG_TRY(attn_core(qkv, kc, vc, 0, 64, (long)E, 1, n_heads, seq_len, q, s));
+    // c_proj (ops.zig:172)
+    ZG_TRY(linear_device(E, E, cpw, cpb, q, 1, out, s));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// attn.hip — KV-cache decode attention: softmax(alpha * q K^T) V for one query per sequence.
+//
+// Replaces scaled_dot_product_attention (reference src/ops.zig:249-307: per head two cblas_sgemm
+// around ops.softmax) and makes the per-step whole-cache transposes of
+// CausalSelfAttention.forward (src/ops.zig:153,158) unnecessary: the cache is addressed through
+// (batch, head, position) strides, so both the model tier's head-major cache and the op tier's
+// [T, H, hd] cache are read in place.
+//
+// HBM-bound and latency-bound: a wave owns 64 cache positions of one head and issues all of its
+// K and V loads (16 B per lane, 16 lanes per 256-B row, fully coalesced) before any arithmetic.
+// Scores are reduced across the 16 lanes of a row with a DPP butterfly reduce-scatter so that
+// every lane ends up owning one position; the softmax statistics are wave reductions; the
+// probabilities are handed back to the lanes that hold the matching V rows with ds_bpermute.
+// Four waves (256 positions) are merged in LDS; partials (o[64], m, l) of the <= ctx/256 splits
+// per head are combined by the consumer (the c_proj GEMV prologue, or attn_merge_kernel).
+#include "zg_kernels.h"
+
+namespace zg {
+
+namespace {
+
+constexpr float kNegBig = -1e30f;
+
+template <typename KV>
+__device__ __forceinline__ f32x4 load_kv4(const KV* p);
+template <>
+__device__ __forceinline__ f32x4 load_kv4<float>(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <>
+__device__ __forceinline__ f32x4 load_kv4<_Float16>(const _Float16* p) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    f32x4 r;
+    r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z; r.w = (float)v.w;
+    return r;
+}
+
+// Butterfly reduce-scatter of 16 values over the 16 lanes of a DPP row: on return lane j of each
+// row holds sum over the row's lanes of s[j].
+__device__ __forceinline__ float row16_reduce_scatter(float (&s)[16], int lr) {
+    // step 1: exchange across lane bit 3 (rotate by 8 == xor 8 inside a 16-lane row)
+    float a8[8];
+    {
+        const bool hi = lr & 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float keep = hi ? s[j + 8] : s[j];
+            const float send = hi ? s[j] : s[j + 8];
+            a8[j] = keep + dpp_row_ror<8>(send);
+        }
+    }
+    // step 2: across lane bit 2 — xor 4 is not one rotation: take both rotations and select
+    float a4[4];
+    {
+        const bool hi = lr & 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = hi ? a8[j + 4] : a8[j];
+            const float send = hi ? a8[j] : a8[j + 4];
+            // partner = lr ^ 4.  row_ror:n delivers lane (i - n) mod 16 to lane i, so lanes with
+            // bit 2 set take ror 4 (from lr - 4) and the others ror 12 (from lr + 4).
+            const float from_lo = dpp_row_ror<4>(send);
+            const float from_hi = dpp_row_ror<12>(send);
+            a4[j] = keep + (hi ? from_lo : from_hi);
+        }
+    }
+    float a2[2];
+    {
+        const bool hi = lr & 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = hi ? a4[j + 2] : a4[j];
+            const float send = hi ? a4[j] : a4[j + 2];
+            const float from_lo = dpp_row_ror<2>(send);
+            const float from_hi = dpp_row_ror<14>(send);
+            a2[j] = keep + (hi ? from_lo : from_hi);
+        }
+    }
+    {
+        const bool hi = lr & 1;
+        const float keep = hi ? a2[1] : a2[0];
+        const float send = hi ? a2[0] : a2[1];
+        const float from_lo = dpp_row_ror<1>(send);
+        const float from_hi = dpp_row_ror<15>(send);
+        return keep + (hi ? from_lo : from_hi);
+    }
+}
+
+// grid (H, max_splits, B), block 256.  Requires head_dim == 64.
+template <typename KV>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_o[4][64];
+    __shared__ float s_m[4], s_l[4];
+    const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
+    const int chunk0 = split * kAttnChunk;
+    if (chunk0 >= T) return;  // nothing to attend to in this split (consumer skips it too)
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+    const int base = chunk0 + wave * 64;
+
+    const KV* K = reinterpret_cast<const KV*>(a.k) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+    const KV* V = reinterpret_cast<const KV*>(a.v) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.n_heads + h) * 64 + lr * 4);
+    const float alpha = 0.125f;  // 1 / sqrt(64), applied to the dot product like sgemm alpha (ops.zig:275)
+
+    float m_w = kNegBig, l_w = 0.0f;
+    f32x4 o4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (base < T) {
+        // ---- all K and V loads up front: position t = base + 4*i + g, dims 4*lr .. 4*lr+3
+        f32x4 k4[16], v4[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = base + 4 * i + g;
+            if (t < T) {
+                k4[i] = load_kv4<KV>(K + (size_t)t * a.stride_t + lr * 4);
+                v4[i] = load_kv4<KV>(V + (size_t)t * a.stride_t + lr * 4);
+            } else {
+                k4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                v4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+        // ---- partial dots, then reduce-scatter: lane (g, j) ends with the score of t = base + 4*j + g
+        float s[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            s[i] = fmaf(q4.x, k4[i].x, fmaf(q4.y, k4[i].y, fmaf(q4.z, k4[i].z, q4.w * k4[i].w)));
+        float sc = row16_reduce_scatter(s, lr) * alpha;
+        const int t_mine = base + 4 * lr + g;
+        if (t_mine >= T) sc = kNegBig;
+        // ---- wave softmax statistics
+        m_w = wave_allmax(sc);
+        const float p = (t_mine < T) ? __expf(sc - m_w) : 0.0f;
+        l_w = wave_allsum(p);
+        // ---- o += p_t * V_t ; p of position (i, g) lives in lane g*16 + i
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pi = __shfl(p, (g << 4) + i, 64);
+            o4.x = fmaf(pi, v4[i].x, o4.x);
+            o4.y = fmaf(pi, v4[i].y, o4.y);
+            o4.z = fmaf(pi, v4[i].z, o4.z);
+            o4.w = fmaf(pi, v4[i].w, o4.w);
+        }
+        // sum the four position groups (lanes 16 apart)
+        o4.x += __shfl_xor(o4.x, 16, 64); o4.y += __shfl_xor(o4.y, 16, 64);
+        o4.z += __shfl_xor(o4.z, 16, 64); o4.w += __shfl_xor(o4.w, 16, 64);
+        o4.x += __shfl_xor(o4.x, 32, 64); o4.y += __shfl_xor(o4.y, 32, 64);
+        o4.z += __shfl_xor(o4.z, 32, 64); o4.w += __shfl_xor(o4.w, 32, 64);
+    }
+    if (lane < 16) *reinterpret_cast<f32x4*>(&s_o[wave][lane * 4]) = o4;
+    if (lane == 0) {
+        s_m[wave] = m_w;
+        s_l[wave] = l_w;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float o = 0.0f, l = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __expf(s_m[w] - M);
+            o = fmaf(sc, s_o[w][lane], o);
+            l = fmaf(sc, s_l[w], l);
+        }
+        float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
+        part[lane] = o;
+        if (lane == 0) {
+            part[64] = M;
+            part[65] = l;
+        }
+    }
+}
+
+// Standalone combine of the split partials (op tier; the model tier folds this into c_proj).
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* part, int n_heads, int max_splits,
+                                                         int seq_len, float* out) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_heads * 64) return;
+    const int h = e >> 6, d = e & 63;
+    const int nsplit = (seq_len + kAttnChunk - 1) / kAttnChunk;
+    const float* p = part + ((size_t)(b * n_heads + h) * max_splits) * kPartStride;
+    float mx = kNegBig;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, p[s * kPartStride + 64]);
+    float o = 0.0f, l = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __expf(p[s * kPartStride + 64] - mx);
+        o = fmaf(w, p[s * kPartStride + d], o);
+        l = fmaf(w, p[s * kPartStride + 65], l);
+    }
+    out[(size_t)b * n_heads * 64 + e] = o / l;
+}
+
+}  // namespace
+
+int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
+    ZG_REQUIRE(a.head_dim == 64, ZG_ERR_UNSUPPORTED, "attention: head_dim %d != 64", a.head_dim);
+    dim3 grid(a.n_heads, a.max_splits, a.batch);
+    if (a.kv_f16) hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, int max_splits,
+                      int seq_len, float* out, hipStream_t s) {
+    ZG_REQUIRE(head_dim == 64, ZG_ERR_UNSUPPORTED, "attention: head_dim %d != 64", head_dim);
+    dim3 grid((n_heads * 64 + 255) / 256, batch);
+    hipLaunchKernelGGL(attn_merge_kernel, grid, dim3(256), 0, s, part, n_heads, max_splits, seq_len, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+}  // namespace zg

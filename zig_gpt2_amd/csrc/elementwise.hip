@@ -1,0 +1,279 @@
+// elementwise.hip — the small ops of reference src/ops.zig as standalone HIP kernels (op tier),
+// plus the decode-step head kernel of the model tier.  All are HBM/latency bound; loads are
+// 16 B per lane where the layout allows.
+#include "zg_kernels.h"
+
+namespace zg {
+
+namespace {
+
+__device__ __forceinline__ float block_allsum(float v, float* s_red) {
+    v = wave_allsum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int w = 0; w < nw; ++w) t += s_red[w];
+    return t;
+}
+
+__device__ __forceinline__ float block_allmax(float v, float* s_red) {
+    v = wave_allmax(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    float t = s_red[0];
+    for (int w = 1; w < nw; ++w) t = fmaxf(t, s_red[w]);
+    return t;
+}
+
+// LayerNorm.forward (src/ops.zig:82-104): one wave per row, in place.
+__global__ __launch_bounds__(256) void layernorm_kernel(float* x, int rows, int n, const float* g,
+                                                        const float* b, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = x + (size_t)row * n;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+        const float v = r[i];
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+    }
+    s1 = wave_allsum(s1);
+    s2 = wave_allsum(s2);
+    const float mean = s1 / (float)n;
+    const float std_ = sqrtf(s2 / (float)n - mean * mean + eps);
+    for (int i = lane; i < n; i += 64) r[i] = (r[i] - mean) / std_ * g[i] + b[i];
+}
+
+// gelu (src/ops.zig:221-228), in place.
+__global__ __launch_bounds__(256) void gelu_kernel(float* x, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    f32x4* x4 = reinterpret_cast<f32x4*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = x4[i];
+        v.x = gelu_ref(v.x); v.y = gelu_ref(v.y); v.z = gelu_ref(v.z); v.w = gelu_ref(v.w);
+        x4[i] = v;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        x[i] = gelu_ref(x[i]);
+}
+
+// softmax (src/ops.zig:231-241): the whole slice is one vector; single workgroup, in place.
+__global__ __launch_bounds__(1024) void softmax_kernel(float* x, size_t n) {
+    __shared__ float s_red[16];
+    float mx = -3.0e38f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, x[i]);
+    mx = block_allmax(mx, s_red);
+    float sum = 0.0f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = __expf(x[i] - mx);
+        x[i] = e;
+        sum += e;
+    }
+    sum = block_allsum(sum, s_red);
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) x[i] = x[i] / sum;
+}
+
+// Embedding.forward (src/ops.zig:59-67): out[i] = weight[idx[i]].
+__global__ __launch_bounds__(256) void embedding_kernel(const float* w, size_t emb_dim, const size_t* idx,
+                                                        size_t n_rows, float* out, int* oob) {
+    const size_t i = blockIdx.x;
+    const size_t id = idx[i];
+    if (id >= n_rows) {
+        if (threadIdx.x == 0) *oob = 1;
+        return;
+    }
+    for (size_t e = threadIdx.x; e < emb_dim; e += blockDim.x) out[i * emb_dim + e] = w[id * emb_dim + e];
+}
+
+// split_qkv (src/ops.zig:177-196): rows x [3E] -> rows x [E].
+__global__ __launch_bounds__(256) void split_qkv_kernel(const float* in, size_t n_embed, size_t split_idx,
+                                                        float* out) {
+    const size_t r = blockIdx.x;
+    for (size_t e = threadIdx.x; e < n_embed; e += blockDim.x)
+        out[r * n_embed + e] = in[r * 3 * n_embed + split_idx * n_embed + e];
+}
+
+// transpose (src/ops.zig:199-216): (b,t,n,h) -> (b,n,t,h); one workgroup per (b,n,t) run of h.
+__global__ __launch_bounds__(64) void transpose_kernel(const float* in, size_t t, size_t n, size_t h, float* out) {
+    const size_t s = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    const float* src = in + b * t * n * h + s * n * h + hh * h;
+    float* dst = out + b * t * n * h + hh * t * h + s * h;
+    for (size_t d = threadIdx.x; d < h; d += blockDim.x) dst[d] = src[d];
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const float* in, float* out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = f32_to_bf16_rne(in[i]);
+}
+
+__device__ __forceinline__ float load_emb(const void* w, int wt, size_t off) {
+    if (wt == WT_BF16) return __uint_as_float((uint32_t)reinterpret_cast<const bf16_t*>(w)[off] << 16);
+    return reinterpret_cast<const float*>(w)[off];
+}
+
+// Head of one decode step (single workgroup).  Follows generate/sample of src/main.zig:322-342
+// with greedy argmax: picks the token fed at position s, records outputs, writes
+// x = wte[token] + wpe[s] (GPT.forward, src/main.zig:179-183), publishes seq_len = s + 1 and
+// advances the step counter so that the same captured graph serves every position.
+__global__ __launch_bounds__(256) void embed_step_kernel(const EmbedArgs a) {
+    __shared__ int s_tok[64];
+    __shared__ float s_bv[4];
+    __shared__ int s_bi[4];
+    const int s = a.ctrl->step;
+    const int mode = a.ctrl->mode;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < a.batch; b0 += 64) {
+        const int nb = min(64, a.batch - b0);
+        for (int bb = 0; bb < nb; ++bb) {
+            const int b = b0 + bb;
+            const int np = a.prompt_len ? a.prompt_len[b] : 0;
+            // finalise the greedy pick of step s-1 if that step produced logits
+            const bool need_argmax = a.finish_only == 2 || ((mode == 0) && (s - 1 >= np) && (s >= 1));
+            int g = 0;
+            if (need_argmax) {  // uniform across the workgroup
+                float bv = -3.0e38f;
+                int bi = 0x7fffffff;
+                const int npart = a.ctrl->n_partials;
+                for (int p = threadIdx.x; p < npart; p += blockDim.x) {
+                    const float v = a.part_val[(size_t)b * a.part_stride + p];
+                    const int i = a.part_idx[(size_t)b * a.part_stride + p];
+                    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(bv, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                __syncthreads();
+                if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+                __syncthreads();
+                bv = s_bv[0]; bi = s_bi[0];
+                for (int w = 1; w < 4; ++w)
+                    if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+                g = bi;
+                if (threadIdx.x == 0) {
+                    if (a.finish_only == 2) a.cur_token[b] = g;  // zg_gpt_argmax
+                    else a.out_tokens[(size_t)b * a.out_stride + (s - 1)] = g;
+                }
+            }
+            if (threadIdx.x == 0 && !a.finish_only) {
+                int tok;
+                if (mode == 1) tok = a.forced[b];
+                else if (s < np) tok = a.prompt[(size_t)b * a.prompt_stride + s];       // main.zig:331-334
+                else if (s == np) tok = a.prompt[(size_t)b * a.prompt_stride + np - 1];  // main.zig:337: old token re-fed
+                else tok = g;
+                if (mode == 0 && s < np) a.out_tokens[(size_t)b * a.out_stride + s] = tok;
+                a.cur_token[b] = tok;
+                s_tok[bb] = tok;
+            }
+        }
+        if (a.finish_only) continue;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * a.n_embed; i += blockDim.x) {
+            const int bb = i / a.n_embed, e = i % a.n_embed;
+            const int tok = s_tok[bb];
+            a.x[(size_t)(b0 + bb) * a.n_embed + e] =
+                load_emb(a.wte, a.weight_type, (size_t)tok * a.n_embed + e) +
+                load_emb(a.wpe, a.weight_type, (size_t)s * a.n_embed + e);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && !a.finish_only) {
+        a.ctrl->seq_len = s + 1;
+        a.ctrl->step = s + 1;
+    }
+}
+
+inline int grid_for(size_t n, int block = 256, int cap = 2048) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)cap ? cap : g);
+}
+
+}  // namespace
+
+int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s) {
+    if (rows == 0) return ZG_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, n, g, b, eps);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_gelu(float* x, size_t n, hipStream_t s) {
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, x, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_softmax(float* x, size_t n, hipStream_t s) {
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(1024), 0, s, x, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_embedding(const float* w, size_t emb_dim, const size_t* idx, size_t n_idx, size_t n_rows,
+                     float* out, int* d_oob, hipStream_t s) {
+    if (n_idx == 0) return ZG_OK;
+    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)n_idx), dim3(256), 0, s, w, emb_dim, idx, n_rows, out, d_oob);
+    ZG_HIP(hipGetLastError());
+    int oob = 0;
+    ZG_HIP(hipMemcpyAsync(&oob, d_oob, sizeof(int), hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    if (oob) {
+        ZG_HIP(hipMemsetAsync(d_oob, 0, sizeof(int), s));
+        zg::set_error("embedding: index out of range (>= %zu rows)", n_rows);
+        return ZG_ERR_SHAPE;
+    }
+    return ZG_OK;
+}
+
+int launch_split_qkv(const float* in, size_t rows, size_t n_embed, size_t split_idx, float* out, hipStream_t s) {
+    if (rows == 0) return ZG_OK;
+    hipLaunchKernelGGL(split_qkv_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, n_embed, split_idx, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_transpose(const float* in, size_t batch, size_t t, size_t n, size_t h, float* out, hipStream_t s) {
+    if (batch * t * n * h == 0) return ZG_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)t, (unsigned)n, (unsigned)batch), dim3(64), 0, s, in, t, n, h, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_embed_step(const EmbedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(embed_step_kernel, dim3(1), dim3(256), 0, s, a);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+}  // namespace zg

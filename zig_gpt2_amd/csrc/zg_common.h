@@ -1,0 +1,96 @@
+// zg_common.h — shared host/device helpers for libzgpt2_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/zgpt2.h"
+
+namespace zg {
+
+// ------------------------------------------------------------------------------ error plumbing
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define ZG_HIP(expr)                                                         \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) return zg::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define ZG_REQUIRE(cond, code, ...)        \
+    do {                                   \
+        if (!(cond)) {                     \
+            zg::set_error(__VA_ARGS__);    \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define ZG_TRY(expr)             \
+    do {                         \
+        int _s = (expr);         \
+        if (_s != ZG_OK) return _s; \
+    } while (0)
+
+// ------------------------------------------------------------------------------ device helpers
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) {
+    return __uint_as_float(packed & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+    uint32_t b = __float_as_uint(x);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+
+// DPP row rotate inside each 16-lane row: every lane reads the lane `n` to its right (cyclic).
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x120 | N, 0xF, 0xF, true));
+}
+
+// Sum over each 16-lane row; every lane of the row receives the total.
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
+    return v;
+}
+
+// Sum over groups of LPR consecutive lanes (LPR in {16, 32, 64}); all lanes get the total.
+template <int LPR>
+__device__ __forceinline__ float group_allsum(float v) {
+    v = row16_allsum(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_allsum(float v) { return group_allsum<64>(v); }
+
+__device__ __forceinline__ float wave_allmax(float v) {
+    v = fmaxf(v, dpp_row_ror<8>(v));
+    v = fmaxf(v, dpp_row_ror<4>(v));
+    v = fmaxf(v, dpp_row_ror<2>(v));
+    v = fmaxf(v, dpp_row_ror<1>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// gelu of src/ops.zig:221-228: 0.5 x (1 + tanh(u)), u = x * 0.7978845608 * (1 + 0.044715 x^2).
+// 0.5 (1 + tanh u) == 1 / (1 + exp(-2u)) exactly; this form keeps relative accuracy in both tails.
+__device__ __forceinline__ float gelu_ref(float x) {
+    const float u = x * 0.7978845608f * (1.0f + 0.044715f * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+}  // namespace zg

@@ -1,0 +1,115 @@
+// zg_kernels.h — host-callable launchers of the HIP kernels (internal to libzgpt2_hip).
+#pragma once
+#include "zg_common.h"
+
+namespace zg {
+
+// Device-side decode control block (lives in the model arena; read by kernels so that one
+// captured hipGraph replays for every position).
+struct StepCtrl {
+    int step;      // 0-based decode step s; sequence length T = s + 1 while a step runs
+    int seq_len;   // T of the step in flight (written by the embed kernel)
+    int mode;      // 0: generate loop (tokens from prompts / previous argmax), 1: forced tokens
+    int n_partials;  // number of lm_head argmax partials per sequence (grid of the lm_head GEMV)
+};
+
+// ------------------------------------------------------------------------------------ GEMV
+enum GemvPrologue { PRO_NONE = 0, PRO_LAYERNORM = 1, PRO_ATTN_MERGE = 2 };
+enum GemvEpilogue { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GELU = 2, EPI_QKV = 3, EPI_ARGMAX = 4 };
+enum WeightType { WT_BF16 = 0, WT_F32 = 1 };
+
+constexpr int kAttnChunk = 256;       // KV positions per attention workgroup (4 waves x 64)
+constexpr int kPartStride = 64 + 2;   // floats per attention partial: o[hd<=64], m, l
+
+struct GemvArgs {
+    // y[m][n] = epilogue( sum_k prologue(x)[m][k] * W[n][k] + bias[n] ),  m < M, n < N
+    const void* W;  // [N][K], bf16 bits or fp32, K contiguous (ops.Linear.weight layout)
+    const float* bias;  // [N] or nullptr
+    int N, K, M;
+    int rows_per_wave;
+    int prologue, epilogue;
+    // PRO_NONE / PRO_LAYERNORM input
+    const float* x;  // [M][x_stride]
+    int x_stride;
+    const float* ln_g;
+    const float* ln_b;
+    float eps;
+    // PRO_ATTN_MERGE input: partials [M][H][max_splits][kPartStride]
+    const float* part;
+    int n_heads, head_dim, max_splits;
+    const StepCtrl* ctrl;  // seq_len for the merge / KV scatter position
+    // EPI_STORE / EPI_RESIDUAL / EPI_GELU
+    float* y;
+    int y_stride;
+    const float* resid;  // may alias y
+    int resid_stride;
+    // EPI_QKV: q [M][E]; caches [M][H][ctx][hd]
+    float* q;
+    void* k_cache;
+    void* v_cache;
+    int ctx;
+    int kv_f16;
+    // EPI_ARGMAX: optional logits [M][logits_stride]; partials [M][gridDim.x]
+    float* logits;
+    int logits_stride;
+    float* part_val;
+    int* part_idx;
+};
+
+// Fills rows_per_wave and returns the grid size for the given problem.
+int gemv_plan(GemvArgs& a);
+int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s);
+
+// ------------------------------------------------------------------------------------ attention
+struct AttnArgs {
+    const float* q;  // [B][H*hd]
+    const void* k;   // element (b,h,t,d) at b*stride_b + h*stride_h + t*stride_t + d
+    const void* v;
+    long stride_b, stride_h, stride_t;
+    int kv_f16;
+    int n_heads, head_dim, batch;
+    const StepCtrl* ctrl;  // seq_len read from ctrl->seq_len when non-null
+    int seq_len;           // used when ctrl == nullptr
+    int max_splits;
+    float* part;  // [B][H][max_splits][kPartStride]
+};
+int launch_attn_decode(const AttnArgs& a, hipStream_t s);
+// Standalone merge (op tier): out[b][h*hd+d] = sum_s w_s o_s / sum_s w_s l_s
+int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, int max_splits,
+                      int seq_len, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------ elementwise
+int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s);
+int launch_gelu(float* x, size_t n, hipStream_t s);
+int launch_softmax(float* x, size_t n, hipStream_t s);
+int launch_embedding(const float* w, size_t emb_dim, const size_t* idx, size_t n_idx, size_t n_rows,
+                     float* out, int* d_oob_flag, hipStream_t s);
+int launch_split_qkv(const float* in, size_t rows, size_t n_embed, size_t split_idx, float* out, hipStream_t s);
+int launch_transpose(const float* in, size_t batch, size_t t, size_t n, size_t h, float* out, hipStream_t s);
+int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);
+int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+
+// Decode-step head kernel: token selection (+ argmax finalisation of the previous step) and
+// x = wte[token] + wpe[pos].
+struct EmbedArgs {
+    StepCtrl* ctrl;
+    const void* wte;  // [V][E] bf16 or fp32
+    const void* wpe;  // [ctx][E]
+    int weight_type;
+    int n_embed, batch, vocab;
+    const int* prompt;       // [B][prompt_stride]
+    int prompt_stride;
+    const int* prompt_len;   // [B]
+    const int* forced;       // [B] (mode 1)
+    int* cur_token;          // [B]
+    int* out_tokens;         // [B][out_stride]
+    int out_stride;
+    const float* part_val;   // [B][n_partials]
+    const int* part_idx;
+    int part_stride;
+    float* x;                // [B][E]
+    int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
+};
+int launch_embed_step(const EmbedArgs& a, hipStream_t s);
+
+}  // namespace zg
