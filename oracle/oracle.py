@@ -26,12 +26,29 @@ def build(force=False):
     return _SO
 
 
+def host_cores():
+    """Usable host cores: affinity mask, clipped by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
         _declare(_lib)
+        # tests: a bounded OpenMP team (oversubscribed teams make the many tiny sgemm calls crawl)
+        _lib.orc_set_num_threads(min(host_cores(), int(os.environ.get("ZGPT2_ORACLE_THREADS", "16"))))
     return _lib
 
 

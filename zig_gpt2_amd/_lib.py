@@ -95,6 +95,15 @@ def load():
         raise RuntimeError(
             f"{SO_PATH} is missing: the HIP extension is required (run `python -c 'import __graft_entry__ as g; g.build()'`)"
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7,
+    # requested by torch as "libamdhip64.so").  If this library pulled in /opt/rocm's copy first, a
+    # later `import torch` would load a second runtime that finds no GPU.  Importing torch first makes
+    # the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already loaded.
+    if os.environ.get("ZGPT2_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(SO_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

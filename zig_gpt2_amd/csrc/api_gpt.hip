@@ -149,7 +149,7 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.out_stride = (int)g->cfg.context_size;
     e.part_val = g->part_val;
     e.part_idx = g->part_idx;
-    e.part_stride = 4096;
+    e.part_stride = g->lm_grid;  // the lm_head GEMV writes partials [batch][gridDim.x]
     e.x = g->x;
     e.finish_only = finish_only;
     return e;
