@@ -186,11 +186,12 @@ int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t 
 
 /* ------------------------------------------------------------------ measurement helpers ---- */
 
-/* Run only the lm_head kernel (ln_f + 50257x768 GEMV + argmax) `iters` times on the current
- * state and return the average device time per launch in microseconds (HIP events on the
- * library stream).  Used by bench.py's roofline line. */
+/* Replay one kernel class of the decode step (layer 0; classes numbered as in
+ * zg_gpt_profile_step: 0 embed ... 6 lm_head) `iters` times back to back from a hipGraph at
+ * seq_len = context/2 and return the average device time per launch in microseconds (launch
+ * boundary included) and the kernel's algorithmic weight bytes.  A warm-cache microbenchmark: the
+ * in-situ numbers are zg_gpt_profile_step's. */
 int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes);
-enum { ZG_TIME_LM_HEAD = 0, ZG_TIME_C_FC = 1, ZG_TIME_ATTN = 2, ZG_TIME_STEP = 3 };
 
 /* Run `iters` consecutive decode steps starting at sequence length seq_len as EAGER launches with a
  * HIP event between every two kernels, and return the average device time in microseconds that

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(_HERE, "lib", "libzgpt2_hip.so")
+SO_PATH = os.environ.get("ZGPT2_LIB") or os.path.join(_HERE, "lib", "libzgpt2_hip.so")  # ZGPT2_LIB: diagnostic builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "zgpt2.h")
 
 _lib = None
@@ -72,7 +72,7 @@ GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16 = 0, 1, 2, 4
 BLOCK_SLOTS = ["ln_1_g", "ln_1_b", "c_attn_w", "c_attn_b", "c_proj_w", "c_proj_b",
                "ln_2_g", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b"]
 TOP_SLOTS = ["wte", "wpe", "ln_f_g", "ln_f_b"]
-TIME_LM_HEAD = 0
+TIME_LM_HEAD = 6
 
 
 def build(force=False):

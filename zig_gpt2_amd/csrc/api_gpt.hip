@@ -45,8 +45,10 @@ struct zg_gpt {
     // pinned host mirrors for small control traffic
     StepCtrl* h_ctrl;
     int* h_ints;  // [batch * ctx] staging for prompts / tokens
-    // graphs
-    hipGraphExec_t graph[2];  // [0] without lm_head, [1] with
+    // graphs: one per (64-position bucket of seq_len, with/without lm_head), captured on first use.
+    // The bucket's upper bound t_hi is baked into the attention / merge kernels so that their loads
+    // do not wait for the exact seq_len (which lives in device memory).
+    std::vector<hipGraphExec_t> graphs;
     hipStream_t graph_stream;
     size_t steps_enqueued;
 };
@@ -114,8 +116,16 @@ void carve(zg_gpt* g, char* base) {
     g->arena_bytes = (cv.off + 255) & ~(size_t)255;
 }
 
-GemvArgs base_gemv(const zg_gpt* g, const void* W, const float* bias, size_t N, size_t K) {
+int bucket_t_hi(const zg_gpt* g, size_t seq_len) {
+    const size_t hi = ((seq_len + 63) / 64) * 64;
+    return (int)(hi < g->cfg.context_size ? hi : g->cfg.context_size);
+}
+
+GemvArgs base_gemv(const zg_gpt* g, const void* W, const float* bias, size_t N, size_t K, int t_hi) {
     GemvArgs a{};
+    a.t_hi = t_hi;
+    a.dbg = ctx().dbg;
+    a.zero = ctx().d_zero;
     a.W = W;
     a.bias = bias;
     a.N = (int)N;
@@ -150,6 +160,7 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.part_val = g->part_val;
     e.part_idx = g->part_idx;
     e.part_stride = g->lm_grid;  // the lm_head GEMV writes partials [batch][gridDim.x]
+    e.n_partials = g->lm_grid;
     e.x = g->x;
     e.finish_only = finish_only;
     return e;
@@ -158,7 +169,7 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
 int enqueue_lm_head(zg_gpt* g, hipStream_t s) {
     const size_t E = g->cfg.n_embed, V = g->cfg.vocab_size;
     // ln_f (main.zig:189) + lm_head = wte, no bias (main.zig:192-194, :312) + greedy partial argmax
-    GemvArgs a = base_gemv(g, g->wte, nullptr, V, E);
+    GemvArgs a = base_gemv(g, g->wte, nullptr, V, E, 0);
     a.prologue = PRO_LAYERNORM;
     a.x = g->x;
     a.x_stride = (int)E;
@@ -194,15 +205,16 @@ inline int prof_mark(StepProf* p, int cls, hipStream_t s) {
 }
 
 // One decode step = GPT.forward (main.zig:178-195) for all sequences.
-int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nullptr) {
+// `only` >= 0 (measurement): launch just that kernel class of layer 0.
+int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1) {
     const size_t E = g->cfg.n_embed;
     ZG_TRY(prof_mark(prof, -1, s));
-    ZG_TRY(launch_embed_step(embed_args(g, 0), s));  // main.zig:179-183 (+ token selection)
+    if (only < 0 || only == 0) ZG_TRY(launch_embed_step(embed_args(g, only == 0 ? 3 : 0), s));  // main.zig:179-183
     ZG_TRY(prof_mark(prof, 0, s));
-    for (size_t l = 0; l < g->cfg.n_layer; ++l) {
+    for (size_t l = 0; l < (only < 0 ? g->cfg.n_layer : 1); ++l) {
         const zg_layer& y = g->layers[l];
-        {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
-            GemvArgs a = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * E, E);
+        if (only < 0 || only == 1) {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
+            GemvArgs a = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * E, E, t_hi);
             a.prologue = PRO_LAYERNORM;
             a.x = g->x;
             a.x_stride = (int)E;
@@ -216,7 +228,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nu
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 1, s));
         }
-        {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
+        if (only < 0 || only == 2) {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
             AttnArgs a{};
             a.q = g->q;
             a.k = y.k_cache;
@@ -229,13 +241,14 @@ int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nu
             a.head_dim = 64;
             a.batch = (int)g->batch;
             a.ctrl = g->ctrl;
+            a.t_hi = t_hi;
             a.max_splits = g->max_splits;
             a.part = g->part;
             ZG_TRY(launch_attn_decode(a, s));
             ZG_TRY(prof_mark(prof, 2, s));
         }
-        {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
-            GemvArgs a = base_gemv(g, y.c_proj_w, y.c_proj_b, E, E);
+        if (only < 0 || only == 3) {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
+            GemvArgs a = base_gemv(g, y.c_proj_w, y.c_proj_b, E, E, t_hi);
             a.prologue = PRO_ATTN_MERGE;
             a.part = g->part;
             a.epilogue = EPI_RESIDUAL;
@@ -247,8 +260,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nu
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 3, s));
         }
-        {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
-            GemvArgs a = base_gemv(g, y.c_fc_w, y.c_fc_b, 4 * E, E);
+        if (only < 0 || only == 4) {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
+            GemvArgs a = base_gemv(g, y.c_fc_w, y.c_fc_b, 4 * E, E, t_hi);
             a.prologue = PRO_LAYERNORM;
             a.x = g->x;
             a.x_stride = (int)E;
@@ -261,8 +274,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nu
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 4, s));
         }
-        {   // mlp c_proj + residual: main.zig:81, :142-145
-            GemvArgs a = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, E, 4 * E);
+        if (only < 0 || only == 5) {   // mlp c_proj + residual: main.zig:81, :142-145
+            GemvArgs a = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, E, 4 * E, t_hi);
             a.prologue = PRO_NONE;
             a.x = g->h4;
             a.x_stride = (int)(4 * E);
@@ -276,45 +289,47 @@ int enqueue_step(zg_gpt* g, bool with_logits, hipStream_t s, StepProf* prof = nu
             ZG_TRY(prof_mark(prof, 5, s));
         }
     }
-    if (with_logits) {
+    if (with_logits && (only < 0 || only == 6)) {
         ZG_TRY(enqueue_lm_head(g, s));
         ZG_TRY(prof_mark(prof, 6, s));
     }
     return ZG_OK;
 }
 
-int ensure_graphs(zg_gpt* g, hipStream_t s) {
-    if (g->flags & ZG_GPT_NO_GRAPH) return ZG_OK;
-    if (g->graph[0] && g->graph_stream == s) return ZG_OK;
-    if (s == nullptr) return ZG_OK;  // the legacy default stream cannot be captured: stay eager
-    for (int i = 0; i < 2; ++i)
-        if (g->graph[i]) {
-            (void)hipGraphExecDestroy(g->graph[i]);
-            g->graph[i] = nullptr;
+void drop_graphs(zg_gpt* g) {
+    for (auto& e : g->graphs)
+        if (e) {
+            (void)hipGraphExecDestroy(e);
+            e = nullptr;
         }
-    for (int i = 0; i < 2; ++i) {
+}
+
+// Run one decode step at sequence length seq_len: replay the graph of its bucket (capturing it on
+// first use), or launch eagerly when graphs are disabled / the stream cannot be captured.
+int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
+    const int t_hi = bucket_t_hi(g, seq_len);
+    if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_step(g, with_logits, t_hi, s);
+    if (g->graph_stream != s) {
+        drop_graphs(g);
+        g->graph_stream = s;
+    }
+    const size_t idx = ((seq_len + 63) / 64 - 1) * 2 + (with_logits ? 1 : 0);
+    if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
+    if (!g->graphs[idx]) {
         hipGraph_t graph = nullptr;
         ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int st = enqueue_step(g, i == 1, s);
+        const int st = enqueue_step(g, with_logits, t_hi, s);
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (st != ZG_OK) {
             if (graph) (void)hipGraphDestroy(graph);
             return st;
         }
         ZG_HIP(e);
-        ZG_HIP(hipGraphInstantiate(&g->graph[i], graph, nullptr, nullptr, 0));
+        ZG_HIP(hipGraphInstantiate(&g->graphs[idx], graph, nullptr, nullptr, 0));
         ZG_HIP(hipGraphDestroy(graph));
     }
-    g->graph_stream = s;
+    ZG_HIP(hipGraphLaunch(g->graphs[idx], s));
     return ZG_OK;
-}
-
-int run_step(zg_gpt* g, bool with_logits, hipStream_t s) {
-    if (g->graph[0] && g->graph_stream == s) {
-        ZG_HIP(hipGraphLaunch(g->graph[with_logits ? 1 : 0], s));
-        return ZG_OK;
-    }
-    return enqueue_step(g, with_logits, s);
 }
 
 int upload_f32(const float* src, size_t n, void* dst, bool as_bf16, hipStream_t s) {
@@ -365,7 +380,6 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     g->wbytes = g->wt == WT_BF16 ? 2 : 4;
     g->kv_f16 = (flags & ZG_GPT_KV_F16) ? 1 : 0;
     g->max_splits = (int)((c.context_size + kAttnChunk - 1) / kAttnChunk);
-    g->graph[0] = g->graph[1] = nullptr;
     g->graph_stream = nullptr;
     carve(g, nullptr);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->arena), g->arena_bytes);
@@ -376,7 +390,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     carve(g, g->arena);
     (void)hipMemset(g->arena + g->weight_region_bytes, 0, g->arena_bytes - g->weight_region_bytes);
     {
-        GemvArgs a = base_gemv(g, g->wte, nullptr, c.vocab_size, c.n_embed);
+        GemvArgs a = base_gemv(g, g->wte, nullptr, c.vocab_size, c.n_embed, 0);
         g->lm_grid = gemv_plan(a);
     }
     if (g->lm_grid > 4096) {
@@ -396,8 +410,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
 int zg_gpt_destroy(zg_gpt* g) {
     if (!g) return ZG_OK;
     (void)hipStreamSynchronize(ctx().stream);
-    for (int i = 0; i < 2; ++i)
-        if (g->graph[i]) (void)hipGraphExecDestroy(g->graph[i]);
+    drop_graphs(g);
     (void)hipFree(g->arena);
     (void)hipHostFree(g->h_ctrl);
     (void)hipHostFree(g->h_ints);
@@ -481,14 +494,13 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
         ZG_REQUIRE(tokens[b] < V, ZG_ERR_SHAPE, "gpt_forward: token %zu >= vocab %zu", tokens[b], V);
         g->h_ints[b] = (int)tokens[b];
     }
-    ZG_TRY(ensure_graphs(g, s));
     g->h_ctrl->step = (int)seq_len - 1;
     g->h_ctrl->seq_len = (int)seq_len;
     g->h_ctrl->mode = 1;
     g->h_ctrl->n_partials = g->lm_grid;
     ZG_HIP(hipMemcpyAsync(g->forced, g->h_ints, g->batch * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
-    ZG_TRY(run_step(g, compute_logits != 0, s));
+    ZG_TRY(run_step(g, compute_logits != 0, seq_len, s));
     if (logits_out) {
         ZG_HIP(hipMemcpyAsync(logits_out, g->logits, g->batch * V * sizeof(float),
                               is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -540,7 +552,6 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
         g->h_ints[B * C + b] = (int)np;
         if (np < min_prompt) min_prompt = np;
     }
-    ZG_TRY(ensure_graphs(g, s));
     g->h_ctrl->step = 0;
     g->h_ctrl->seq_len = 0;
     g->h_ctrl->mode = 0;
@@ -548,7 +559,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
-    for (size_t st = 0; st < n_steps; ++st) ZG_TRY(run_step(g, st >= min_prompt, s));  // main.zig:330-338
+    for (size_t st = 0; st < n_steps; ++st) ZG_TRY(run_step(g, st >= min_prompt, st + 1, s));  // main.zig:330-338
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
     g->steps_enqueued = n_steps;
     return ZG_OK;
@@ -592,7 +603,7 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
         prof.n = 0;
-        ZG_TRY(enqueue_step(g, true, s, &prof));  // eager launches; the embed kernel advances the position
+        ZG_TRY(enqueue_step(g, true, bucket_t_hi(g, seq_len + it), s, &prof));  // eager; the embed kernel advances the position
         ZG_HIP(hipStreamSynchronize(s));
         for (size_t i = 1; i < prof.n; ++i) {
             float ms = 0.0f;
@@ -607,36 +618,66 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
 
 int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes) {
     ZG_TRY(require_init());
-    ZG_REQUIRE(g && avg_us && iters > 0, ZG_ERR_ARG, "time_kernel: bad argument");
+    ZG_REQUIRE(g && avg_us && iters > 0 && which >= 0 && which <= 6, ZG_ERR_ARG, "time_kernel: bad argument");
     hipStream_t s = ctx().stream;
+    ZG_REQUIRE(s != nullptr, ZG_ERR_UNSUPPORTED, "time_kernel needs a capturable stream");
+    const size_t E = g->cfg.n_embed, wb = g->wbytes;
+    const size_t bytes_tab[7] = {0, 3 * E * E * wb, 0, E * E * wb, 4 * E * E * wb, 4 * E * E * wb, g->cfg.vocab_size * E * wb};
+    // control block: a mid-context position so that the attention kernel has work
+    const size_t T = g->cfg.context_size / 2 > 0 ? g->cfg.context_size / 2 : 1;
+    ZG_HIP(hipStreamSynchronize(s));
+    g->h_ctrl->step = (int)T - 1;
+    g->h_ctrl->seq_len = (int)T;
+    g->h_ctrl->mode = 1;
+    g->h_ctrl->n_partials = g->lm_grid;
+    ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    const int chain = 64;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int st = ZG_OK;
+    for (int i = 0; i < chain && st == ZG_OK; ++i) st = enqueue_step(g, true, bucket_t_hi(g, T), s, nullptr, which);
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (st != ZG_OK) return st;
+    ZG_HIP(ce);
+    ZG_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipEvent_t e0, e1;
     ZG_HIP(hipEventCreate(&e0));
     ZG_HIP(hipEventCreate(&e1));
-    const size_t E = g->cfg.n_embed;
-    size_t bytes = 0;
-    int st = ZG_OK;
+    ZG_HIP(hipGraphLaunch(exec, s));
     ZG_HIP(hipStreamSynchronize(s));
+    const int reps = (iters + chain - 1) / chain;
     ZG_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < iters && st == ZG_OK; ++i) {
-        switch (which) {
-            case ZG_TIME_LM_HEAD:
-                st = enqueue_lm_head(g, s);
-                bytes = g->cfg.vocab_size * E * g->wbytes;
-                break;
-            default:
-                set_error("time_kernel: unknown kernel %d", which);
-                st = ZG_ERR_ARG;
-        }
-    }
+    for (int r = 0; r < reps; ++r) ZG_HIP(hipGraphLaunch(exec, s));
     ZG_HIP(hipEventRecord(e1, s));
     ZG_HIP(hipEventSynchronize(e1));
     float ms = 0.0f;
     ZG_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    *avg_us = ms * 1000.0f / (float)iters;
-    if (algorithmic_bytes) *algorithmic_bytes = bytes;
-    return st;
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    *avg_us = ms * 1000.0f / (float)(reps * chain);
+    if (algorithmic_bytes) *algorithmic_bytes = bytes_tab[which];
+    return ZG_OK;
 }
+
+#ifdef ZG_STAMPS
+// Diagnostic build only: (re)arm the timestamp buffer / read it back (count, then 10 words per record).
+int zg_debug_stamps_begin(void) {
+    ZG_TRY(require_init());
+    Ctx& c = ctx();
+    const size_t bytes = (16 + 10 * 4096) * sizeof(unsigned long long);
+    if (!c.dbg) ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.dbg), bytes));
+    ZG_HIP(hipMemset(c.dbg, 0, bytes));
+    return ZG_OK;
+}
+int zg_debug_stamps_read(unsigned long long* out, size_t n_words) {
+    ZG_TRY(require_init());
+    ZG_HIP(hipDeviceSynchronize());
+    ZG_HIP(hipMemcpy(out, ctx().dbg, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ZG_OK;
+}
+#endif
 
 }  // extern "C"

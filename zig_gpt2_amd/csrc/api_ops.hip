@@ -127,7 +127,7 @@ static int linear_device(size_t in_f, size_t out_f, const float* w, const float*
     if (m == 0 || out_f == 0) return ZG_OK;
     ZG_REQUIRE(in_f > 0 && in_f <= 8192, ZG_ERR_UNSUPPORTED, "Linear: in_features %zu outside 1..8192", in_f);
     size_t mb = 8;
-    while (mb > 1 && mb * in_f * sizeof(float) > 160 * 1024) mb >>= 1;
+    while (mb > 1 && (mb * in_f + 8 * mb + 64) * sizeof(float) > 160 * 1024) mb >>= 1;
     for (size_t m0 = 0; m0 < m; m0 += mb) {
         GemvArgs a{};
         a.W = w;
@@ -141,6 +141,7 @@ static int linear_device(size_t in_f, size_t out_f, const float* w, const float*
         a.x_stride = (int)in_f;
         a.y = y + m0 * out_f;
         a.y_stride = (int)out_f;
+        a.zero = ctx().d_zero;
         const int grid = gemv_plan(a);
         ZG_TRY(launch_gemv(a, WT_F32, grid, s));
     }
@@ -165,6 +166,7 @@ static int attn_core(const float* q, const float* k, const float* v, long stride
     a.batch = (int)batch;
     a.ctrl = nullptr;
     a.seq_len = (int)seq_len;
+    a.t_hi = (int)seq_len;
     a.max_splits = splits;
     a.part = c.attn_part;
     ZG_TRY(launch_attn_decode(a, s));
@@ -199,6 +201,8 @@ int zg_init_ex(int device, size_t staging_bytes) {
     ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.stage), c.stage_cap));
     ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_flag), sizeof(int)));
     ZG_HIP(hipMemset(c.d_flag, 0, sizeof(int)));
+    ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_zero), 64));
+    ZG_HIP(hipMemset(c.d_zero, 0, 64));
     c.attn_part_floats = (size_t)4 << 20;
     ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.attn_part), c.attn_part_floats * sizeof(float)));
     c.stage_off = 0;
@@ -224,6 +228,7 @@ int zg_shutdown(void) {
     c.registry.clear();
     (void)hipFree(c.stage);
     (void)hipFree(c.d_flag);
+    (void)hipFree(c.d_zero);
     (void)hipFree(c.attn_part);
     (void)hipStreamDestroy(c.own_stream);
     c = Ctx();

@@ -93,9 +93,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_o[4][64];
     __shared__ float s_m[4], s_l[4];
     const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    // t_hi: launch-time upper bound of the sequence length (seq_len itself in the op tier, the
+    // 64-position bucket of the captured graph in the model tier).  Every K/V load below depends
+    // only on t_hi, so it is in flight while the exact seq_len is still being fetched from the
+    // device control block; seq_len is needed for masking alone.
+    const int t_hi = a.t_hi;
     const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
     const int chunk0 = split * kAttnChunk;
-    if (chunk0 >= T) return;  // nothing to attend to in this split (consumer skips it too)
+    if (chunk0 >= t_hi) return;  // nothing to attend to in this split (consumer skips it too)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, g = lane >> 4;
@@ -108,13 +113,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
     float m_w = kNegBig, l_w = 0.0f;
     f32x4 o4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (base < T) {
+    if (base < t_hi) {
         // ---- all K and V loads up front: position t = base + 4*i + g, dims 4*lr .. 4*lr+3
         f32x4 k4[16], v4[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int t = base + 4 * i + g;
-            if (t < T) {
+            if (t < t_hi) {
                 k4[i] = load_kv4<KV>(K + (size_t)t * a.stride_t + lr * 4);
                 v4[i] = load_kv4<KV>(V + (size_t)t * a.stride_t + lr * 4);
             } else {
@@ -197,7 +202,10 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* part, int 
 
 int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     ZG_REQUIRE(a.head_dim == 64, ZG_ERR_UNSUPPORTED, "attention: head_dim %d != 64", a.head_dim);
-    dim3 grid(a.n_heads, a.max_splits, a.batch);
+    ZG_REQUIRE(a.t_hi >= 1, ZG_ERR_ARG, "attention: t_hi not set");
+    const int splits = (a.t_hi + kAttnChunk - 1) / kAttnChunk;
+    ZG_REQUIRE(splits <= a.max_splits, ZG_ERR_ARG, "attention: t_hi %d needs %d splits > %d", a.t_hi, splits, a.max_splits);
+    dim3 grid(a.n_heads, splits, a.batch);
     if (a.kv_f16) hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a);
     ZG_HIP(hipGetLastError());

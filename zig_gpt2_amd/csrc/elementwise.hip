@@ -127,71 +127,76 @@ __device__ __forceinline__ float load_emb(const void* w, int wt, size_t off) {
 // with greedy argmax: picks the token fed at position s, records outputs, writes
 // x = wte[token] + wpe[s] (GPT.forward, src/main.zig:179-183), publishes seq_len = s + 1 and
 // advances the step counter so that the same captured graph serves every position.
+// Latency-bound: the argmax partials of the previous step are fetched speculatively together with
+// the control words (one memory round trip), one wave per sequence; only the wte row depends on
+// the chosen token (second round trip).
 __global__ __launch_bounds__(256) void embed_step_kernel(const EmbedArgs a) {
-    __shared__ int s_tok[64];
-    __shared__ float s_bv[4];
-    __shared__ int s_bi[4];
+    __shared__ int s_tok[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = a.ctrl->step;
     const int mode = a.ctrl->mode;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b0 = 0; b0 < a.batch; b0 += 64) {
-        const int nb = min(64, a.batch - b0);
-        for (int bb = 0; bb < nb; ++bb) {
-            const int b = b0 + bb;
-            const int np = a.prompt_len ? a.prompt_len[b] : 0;
-            // finalise the greedy pick of step s-1 if that step produced logits
-            const bool need_argmax = a.finish_only == 2 || ((mode == 0) && (s - 1 >= np) && (s >= 1));
-            int g = 0;
-            if (need_argmax) {  // uniform across the workgroup
-                float bv = -3.0e38f;
-                int bi = 0x7fffffff;
-                const int npart = a.ctrl->n_partials;
-                for (int p = threadIdx.x; p < npart; p += blockDim.x) {
-                    const float v = a.part_val[(size_t)b * a.part_stride + p];
-                    const int i = a.part_idx[(size_t)b * a.part_stride + p];
-                    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
-                }
+    const int npart = a.n_partials;
+    for (int b = wave; b < a.batch; b += 4) {
+        // speculative fetch of this sequence's partial maxima (valid memory whether or not needed)
+        float bv = -3.0e38f;
+        int bi = 0x7fffffff;
+        for (int p = lane; p < npart; p += 64) {
+            const float v = a.part_val[(size_t)b * a.part_stride + p];
+            const int i = a.part_idx[(size_t)b * a.part_stride + p];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+        const int np = a.prompt_len ? a.prompt_len[b] : 0;
+        const int p_cur = a.prompt[(size_t)b * a.prompt_stride + min(s, a.prompt_stride - 1)];
+        const int p_last = a.prompt[(size_t)b * a.prompt_stride + max(min(np, a.prompt_stride) - 1, 0)];
+        const int forced = a.forced[b];
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const float ov = __shfl_xor(bv, off, 64);
-                    const int oi = __shfl_xor(bi, off, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                __syncthreads();
-                if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
-                __syncthreads();
-                bv = s_bv[0]; bi = s_bi[0];
-                for (int w = 1; w < 4; ++w)
-                    if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
-                g = bi;
-                if (threadIdx.x == 0) {
-                    if (a.finish_only == 2) a.cur_token[b] = g;  // zg_gpt_argmax
-                    else a.out_tokens[(size_t)b * a.out_stride + (s - 1)] = g;
-                }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const int g = bi;
+        // the greedy pick of step s-1 exists iff that step ran lm_head (main.zig:337)
+        const bool have_pick = a.finish_only == 2 || ((mode == 0) && (s >= 1) && (s - 1 >= np));
+        if (lane == 0) {
+            if (have_pick) {
+                if (a.finish_only == 2) a.cur_token[b] = g;  // zg_gpt_argmax
+                else a.out_tokens[(size_t)b * a.out_stride + (s - 1)] = g;
             }
-            if (threadIdx.x == 0 && !a.finish_only) {
+            if (a.finish_only == 0 || a.finish_only == 3) {
                 int tok;
-                if (mode == 1) tok = a.forced[b];
-                else if (s < np) tok = a.prompt[(size_t)b * a.prompt_stride + s];       // main.zig:331-334
-                else if (s == np) tok = a.prompt[(size_t)b * a.prompt_stride + np - 1];  // main.zig:337: old token re-fed
+                if (mode == 1) tok = forced;
+                else if (s < np) tok = p_cur;      // main.zig:331-334: prompt token s
+                else if (s == np) tok = p_last;    // main.zig:337: the previous token is fed again
                 else tok = g;
                 if (mode == 0 && s < np) a.out_tokens[(size_t)b * a.out_stride + s] = tok;
                 a.cur_token[b] = tok;
-                s_tok[bb] = tok;
+                s_tok[b] = tok;
             }
         }
-        if (a.finish_only) continue;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb * a.n_embed; i += blockDim.x) {
-            const int bb = i / a.n_embed, e = i % a.n_embed;
-            const int tok = s_tok[bb];
-            a.x[(size_t)(b0 + bb) * a.n_embed + e] =
-                load_emb(a.wte, a.weight_type, (size_t)tok * a.n_embed + e) +
-                load_emb(a.wpe, a.weight_type, (size_t)s * a.n_embed + e);
-        }
-        __syncthreads();
     }
-    if (threadIdx.x == 0 && !a.finish_only) {
+    if (a.finish_only == 1 || a.finish_only == 2) return;
+    __syncthreads();
+    const int total4 = a.batch * (a.n_embed >> 2);
+    for (int i = threadIdx.x; i < total4; i += blockDim.x) {
+        const int b = i / (a.n_embed >> 2), e = (i % (a.n_embed >> 2)) * 4;
+        const int tok = s_tok[b];
+        f32x4 o;
+        if (a.weight_type == WT_BF16) {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.wte) + (size_t)tok * a.n_embed + e);
+            const u32x2 p = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.wpe) + (size_t)s * a.n_embed + e);
+            o.x = bf16_lo(t.x) + bf16_lo(p.x);
+            o.y = bf16_hi(t.x) + bf16_hi(p.x);
+            o.z = bf16_lo(t.y) + bf16_lo(p.y);
+            o.w = bf16_hi(t.y) + bf16_hi(p.y);
+        } else {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.wte) + (size_t)tok * a.n_embed + e);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.wpe) + (size_t)s * a.n_embed + e);
+            o = t + p;
+        }
+        *reinterpret_cast<f32x4*>(a.x + (size_t)b * a.n_embed + e) = o;
+    }
+    if (threadIdx.x == 0 && a.finish_only == 0) {
         a.ctrl->seq_len = s + 1;
         a.ctrl->step = s + 1;
     }

@@ -15,6 +15,25 @@
 //             EPI_ARGMAX      greedy sampler partial argmax        (replaces src/main.zig:198-207)
 #include "zg_kernels.h"
 
+// Diagnostic build (-DZG_STAMPS): wave 0 of the first and of the last workgroup record s_memtime at
+// fixed points of the kernel and append them to GemvArgs::dbg.  Compiled out of the product build.
+#ifdef ZG_STAMPS
+#define ZG_STAMP_DECL() unsigned long long zg_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define ZG_STAMP(i) zg_ts[i] = __builtin_amdgcn_s_memtime()
+#define ZG_STAMP_FLUSH()                                                                              \
+    if (a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {             \
+        const unsigned long long slot = atomicAdd(a.dbg, 1ull);                                       \
+        unsigned long long* d = a.dbg + 16 + slot * 10;                                               \
+        for (int i = 0; i < 8; ++i) d[i] = zg_ts[i];                                                  \
+        d[8] = blockIdx.x;                                                                            \
+        d[9] = __builtin_amdgcn_s_memtime();                                                          \
+    }
+#else
+#define ZG_STAMP_DECL()
+#define ZG_STAMP(i)
+#define ZG_STAMP_FLUSH()
+#endif
+
 namespace zg {
 
 namespace {
@@ -89,28 +108,6 @@ __device__ __forceinline__ float dot8(const W8& w, const W8& x, float acc) {
     return acc;
 }
 
-// Merged attention output for elements [e0, e0+8) of sequence m (all inside one head):
-// out = sum_s exp(m_s - M) o_s / sum_s exp(m_s - M) l_s over the splits that saw keys.
-__device__ __forceinline__ W8 merge_attn8(const GemvArgs& a, int m, int e0, int nsplit) {
-    const int h = e0 / a.head_dim, d0 = e0 % a.head_dim;
-    const float* p = a.part + ((size_t)(m * a.n_heads + h) * a.max_splits) * kPartStride;
-    float mx = -1e30f;
-    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, p[s * kPartStride + 64]);
-    W8 o = zero_w8();
-    float l = 0.0f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float w = __expf(p[s * kPartStride + 64] - mx);
-        l = fmaf(w, p[s * kPartStride + 65], l);
-        const float* os = p + s * kPartStride + d0;  // 8-B aligned (kPartStride is even)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.v[j] = fmaf(w, os[j], o.v[j]);
-    }
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] *= inv;
-    return o;
-}
-
 struct Best {
     float val;
     int idx;
@@ -134,14 +131,16 @@ __device__ __forceinline__ void kv_store(void* cache, size_t off, float v) {
     reinterpret_cast<KV*>(cache)[off] = (KV)v;
 }
 
-__device__ __forceinline__ void epilogue_row(const GemvArgs& a, int m, int n, float acc, int pos, Best& best) {
-    float v = acc + (a.bias ? a.bias[n] : 0.0f);
+// bias_n / resid_mn were fetched together with the row's weights (no dependent round trip here).
+__device__ __forceinline__ void epilogue_row(const GemvArgs& a, int m, int n, float acc, float bias_n,
+                                             float resid_mn, int pos, Best& best) {
+    float v = acc + bias_n;
     switch (a.epilogue) {
         case EPI_STORE:
             a.y[(size_t)m * a.y_stride + n] = v;
             break;
         case EPI_RESIDUAL:
-            a.y[(size_t)m * a.y_stride + n] = v + a.resid[(size_t)m * a.resid_stride + n];
+            a.y[(size_t)m * a.y_stride + n] = v + resid_mn;
             break;
         case EPI_GELU:
             a.y[(size_t)m * a.y_stride + n] = gelu_ref(v);
@@ -172,176 +171,345 @@ __device__ __forceinline__ void epilogue_row(const GemvArgs& a, int m, int n, fl
     }
 }
 
+// Merged attention output for elements [e0, e0+4) of sequence m: all loads issued before any math.
+__device__ __forceinline__ f32x4 merge_attn4(const GemvArgs& a, int m, int e0, int nsplit) {
+    const int h = e0 / a.head_dim, d0 = e0 % a.head_dim;
+    const float* p = a.part + ((size_t)(m * a.n_heads + h) * a.max_splits) * kPartStride;
+    constexpr int MAXS = 4;  // ctx 1024 / 256; more splits fall back to the loop below
+    if (nsplit <= MAXS) {
+        float ms[MAXS], ls[MAXS];
+        float o[MAXS][4];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {  // branch-free: surplus splits re-read the last valid one ...
+            const float* ps = p + min(s, nsplit - 1) * kPartStride;
+            ms[s] = ps[64];
+            ls[s] = ps[65];
+            const float2 lo = *reinterpret_cast<const float2*>(ps + d0);      // 8-B aligned: kPartStride
+            const float2 hi = *reinterpret_cast<const float2*>(ps + d0 + 2);  // and d0 are even
+            o[s][0] = lo.x; o[s][1] = lo.y; o[s][2] = hi.x; o[s][3] = hi.y;
+        }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s >= nsplit) ms[s] = -1e30f;  // ... and get weight exp(-1e30 - max) == 0
+        const float mx = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
+        float l = 0.0f;
+        float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const float w = __expf(ms[s] - mx);
+            l = fmaf(w, ls[s], l);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = fmaf(w, o[s][j], r[j]);
+        }
+        const float inv = 1.0f / l;
+        return f32x4{r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv};
+    }
+    float mx = -1e30f;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, p[s * kPartStride + 64]);
+    float l = 0.0f;
+    float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __expf(p[s * kPartStride + 64] - mx);
+        l = fmaf(w, p[s * kPartStride + 65], l);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = fmaf(w, p[s * kPartStride + d0 + j], r[j]);
+    }
+    const float inv = 1.0f / l;
+    return f32x4{r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv};
+}
+
+// Branch-free: out-of-range rows / chunks are clamped to a valid address instead of predicated, so the
+// loads stay in straight-line code and the compiler can wait for them with counted vmcnt (predicated
+// loads sit in exec-masked branches, after which it falls back to vmcnt(0) and the pass pipeline
+// collapses).  A clamped chunk multiplies an input that is zero; a clamped row's result is discarded.
+template <typename WT, int LPR, int CPL>
+__device__ __forceinline__ void load_pass(Raw<WT> (&w)[CPL], const WT* W, int K, int nch, int row, int n_rows,
+                                          int lr) {
+    const WT* wp = W + (size_t)min(row, n_rows - 1) * K;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) w[i] = load_raw(wp, min(lr + LPR * i, nch - 1));
+}
+
+// Per-row epilogue operands, requested together with the row's weights.
+template <int MT>
+struct RowExtra {
+    float bias;
+    float resid[MT];
+};
+template <int MT>
+__device__ __forceinline__ RowExtra<MT> load_extra(const GemvArgs& a, int epilogue, int M, int N, int r) {
+    RowExtra<MT> e;
+    const int rr = min(r, N - 1);
+    e.bias = *(a.bias ? a.bias + rr : a.zero);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        e.resid[m] = *((epilogue == EPI_RESIDUAL && m < M) ? a.resid + (size_t)m * a.resid_stride + rr : a.zero);
+    return e;
+}
+
 // One workgroup = 4 waves; each wave owns rows [gw * rows_per_wave, +rows_per_wave).
-// LPR lanes share one row (64 / LPR rows per pass, two passes in flight), CPL 16-B chunks per lane.
+// LPR lanes share one row (RPP = 64 / LPR rows per pass); CPL 16-B chunks per lane per row.
+//
+// Every kernel of a decode step except lm_head is bound by its chain of dependent memory round
+// trips, not by bandwidth, so the structure minimises that chain:
+//   * the hot scalars (W, x, N, K, ...) are separate leading kernel arguments so that they are
+//     pre-loaded into SGPRs with the wave (kernarg preload) instead of fetched by s_load;
+//   * the first pass of weights is requested before anything else;
+//   * M == 1: each WAVE builds the transformed input row (LayerNorm / head merge) for itself in a
+//     private LDS strip with wave-level reductions only — no workgroup barrier, and the input is
+//     fetched 4x per workgroup instead of once per 16-lane group (which made hundreds of waves
+//     hammer the same few cache lines).  M > 1: one cooperative build per workgroup;
+//   * bias / residual operands of a row travel with the row's weights;
+//   * passes are software-pipelined one deep (next pass in flight while this one is reduced).
 template <typename WT, int MT, int LPR, int CPL, bool ARGMAX>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, const float* __restrict__ xin,
+                                                   int N, int K, int M, int rows_per_wave, int prologue,
+                                                   int epilogue, const float* __restrict__ ln_g,
+                                                   const float* __restrict__ ln_b, const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RPP = 64 / LPR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool XREG = (MT == 1) && (CPL <= 8);  // input row cached in registers
+    constexpr bool PERWAVE = (MT == 1);             // wave-private prologue, no barrier
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane % LPR, rsub = lane / LPR;
-    const int K = a.K, N = a.N, nch = K >> 3;
-    const WT* W = reinterpret_cast<const WT*>(a.W);
-    const int T = a.ctrl ? a.ctrl->seq_len : 1;
-    const int pos = T - 1;
+    const int nch = K >> 3, nq = K >> 2;
+    const WT* W = reinterpret_cast<const WT*>(Wv);
+    float* xs = PERWAVE ? smem + (size_t)wave * K : smem;          // [MT][K] (per wave when M == 1)
+    float* red = smem + (size_t)(PERWAVE ? 4 : MT) * K;             // cross-wave scratch
 
     const int gw = blockIdx.x * 4 + wave;
-    const int row_begin = gw * a.rows_per_wave;
-    const int row_end = min(row_begin + a.rows_per_wave, N);
+    const int row_begin = gw * rows_per_wave;
+    const int row_end = min(row_begin + rows_per_wave, N);
 
-    // ---------------------------------------------------------------- prologue
-    constexpr bool XREG = (MT == 1) && (CPL <= 8);  // input row cached in registers
-    W8 xr[XREG ? CPL : 1];
-    if constexpr (XREG) {
-        // Register path: every LPR-lane group builds the (transformed) input row in the same
-        // chunk layout it will use against the weights.  No LDS, no barrier.
-        if (a.prologue == PRO_ATTN_MERGE) {
-            const int nsplit = (T + kAttnChunk - 1) / kAttnChunk;
+    // ---- 0. first pass of weights (+ its epilogue operands): independent of every other input
+    Raw<WT> wa[CPL], wb[CPL];
+    RowExtra<MT> ea, eb;
+    ZG_STAMP_DECL();
+    ZG_STAMP(0);
+    load_pass<WT, LPR, CPL>(wa, W, K, nch, row_begin + rsub, N, lr);
+    ea = load_extra<MT>(a, epilogue, M, N, row_begin + rsub);
+
+    // position-dependent scalar (consumed late: merge split count when t_hi == 0, KV scatter position)
+    const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    ZG_STAMP(1);
+
+    // ---- 1. prologue: build the (transformed) input rows in LDS
+    if constexpr (PERWAVE) {
+        f32x4* xw4 = reinterpret_cast<f32x4*>(xs);
+        if (prologue == PRO_LAYERNORM && nq <= 256) {
+            f32x4 v[4], g4[4], b4[4];
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                const int c = lr + LPR * i;
-                xr[i] = (c < nch) ? merge_attn8(a, 0, c * 8, nsplit) : zero_w8();
+            for (int j = 0; j < 4; ++j) {  // branch-free: clamp the index, zero the surplus afterwards
+                const int i = lane + 64 * j, ic = min(i, nq - 1);
+                v[j] = reinterpret_cast<const f32x4*>(xin)[ic];
+                g4[j] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+                b4[j] = reinterpret_cast<const f32x4*>(ln_b)[ic];
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane + 64 * j >= nq) v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // single pass sum / sum of squares; std = sqrt(E[x^2] - mean^2 + eps): ops.zig:88-95
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t1 += v[j].x + v[j].y + v[j].z + v[j].w;
+                t2 = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, t2))));
+            }
+            t1 = wave_allsum(t1);
+            t2 = wave_allsum(t2);
+            ZG_STAMP(2);
+            const float mean = t1 / (float)K;
+            const float rstd = 1.0f / sqrtf(t2 / (float)K - mean * mean + a.eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j;
+                if (i < nq) {
+                    f32x4 o;
+                    o.x = fmaf((v[j].x - mean) * rstd, g4[j].x, b4[j].x);
+                    o.y = fmaf((v[j].y - mean) * rstd, g4[j].y, b4[j].y);
+                    o.z = fmaf((v[j].z - mean) * rstd, g4[j].z, b4[j].z);
+                    o.w = fmaf((v[j].w - mean) * rstd, g4[j].w, b4[j].w);
+                    xw4[i] = o;
+                }
+            }
+        } else if (prologue == PRO_LAYERNORM) {
+            float t1 = 0.0f, t2 = 0.0f;
+            for (int k = lane; k < K; k += 64) {
+                const float val = xin[k];
+                xs[k] = val;
+                t1 += val;
+                t2 = fmaf(val, val, t2);
+            }
+            t1 = wave_allsum(t1);
+            t2 = wave_allsum(t2);
+            const float mean = t1 / (float)K;
+            const float rstd = 1.0f / sqrtf(t2 / (float)K - mean * mean + a.eps);
+            for (int k = lane; k < K; k += 64) xs[k] = fmaf((xs[k] - mean) * rstd, ln_g[k], ln_b[k]);
+        } else if (prologue == PRO_ATTN_MERGE) {
+            const int t_hi = a.t_hi > 0 ? a.t_hi : T;
+            const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
+            for (int i = lane; i < nq; i += 64) xw4[i] = merge_attn4(a, 0, i * 4, nsplit);
+        } else {
+            for (int i = lane; i < nq; i += 64) xw4[i] = reinterpret_cast<const f32x4*>(xin)[i];
+        }
+        // same-wave LDS traffic is ordered: no barrier between the strip's writes and reads below
+    } else {
+        if (prologue == PRO_LAYERNORM && nq <= 512) {
+            f32x4 v[MT][2], g4[2], b4[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;
+                if (i < nq) {
+                    g4[j] = reinterpret_cast<const f32x4*>(ln_g)[i];
+                    b4[j] = reinterpret_cast<const f32x4*>(ln_b)[i];
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    v[m][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (i < nq && m < M) v[m][j] = reinterpret_cast<const f32x4*>(xin + (size_t)m * a.x_stride)[i];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    t1 += v[m][j].x + v[m][j].y + v[m][j].z + v[m][j].w;
+                    t2 = fmaf(v[m][j].x, v[m][j].x, fmaf(v[m][j].y, v[m][j].y, fmaf(v[m][j].z, v[m][j].z, fmaf(v[m][j].w, v[m][j].w, t2))));
+                }
+                t1 = wave_allsum(t1);
+                t2 = wave_allsum(t2);
+                if (lane == 0) {
+                    red[(wave * MT + m) * 2] = t1;
+                    red[(wave * MT + m) * 2 + 1] = t2;
+                }
+            }
+            __syncthreads();
+            ZG_STAMP(2);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float s1 = red[m * 2] + red[(MT + m) * 2] + red[(2 * MT + m) * 2] + red[(3 * MT + m) * 2];
+                const float s2 = red[m * 2 + 1] + red[(MT + m) * 2 + 1] + red[(2 * MT + m) * 2 + 1] + red[(3 * MT + m) * 2 + 1];
+                const float mean = s1 / (float)K;
+                const float rstd = 1.0f / sqrtf(s2 / (float)K - mean * mean + a.eps);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int i = tid + 256 * j;
+                    if (i < nq) {
+                        f32x4 o;
+                        o.x = fmaf((v[m][j].x - mean) * rstd, g4[j].x, b4[j].x);
+                        o.y = fmaf((v[m][j].y - mean) * rstd, g4[j].y, b4[j].y);
+                        o.z = fmaf((v[m][j].z - mean) * rstd, g4[j].z, b4[j].z);
+                        o.w = fmaf((v[m][j].w - mean) * rstd, g4[j].w, b4[j].w);
+                        reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = o;
+                    }
+                }
+            }
+        } else if (prologue == PRO_LAYERNORM) {
+            for (int m = wave; m < MT; m += 4) {  // wide rows: one wave per row, two sweeps
+                float* xm = xs + (size_t)m * K;
+                const float* x = xin + (size_t)m * a.x_stride;
+                float t1 = 0.0f, t2 = 0.0f;
+                for (int k = lane; k < K; k += 64) {
+                    const float val = (m < M) ? x[k] : 0.0f;
+                    xm[k] = val;
+                    t1 += val;
+                    t2 = fmaf(val, val, t2);
+                }
+                t1 = wave_allsum(t1);
+                t2 = wave_allsum(t2);
+                const float mean = t1 / (float)K;
+                const float rstd = 1.0f / sqrtf(t2 / (float)K - mean * mean + a.eps);
+                for (int k = lane; k < K; k += 64) xm[k] = fmaf((xm[k] - mean) * rstd, ln_g[k], ln_b[k]);
+            }
+        } else if (prologue == PRO_ATTN_MERGE) {
+            const int t_hi = a.t_hi > 0 ? a.t_hi : T;
+            const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                for (int i = tid; i < nq; i += 256) {
+                    f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (m < M) o = merge_attn4(a, m, i * 4, nsplit);
+                    reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = o;
+                }
         } else {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                const int c = lr + LPR * i;
-                xr[i] = (c < nch) ? load_x8(a.x + c * 8) : zero_w8();
-            }
-            if (a.prologue == PRO_LAYERNORM) {
-                // single pass sum / sum of squares, std = sqrt(E[x^2] - mean^2 + eps): ops.zig:88-95
-                float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < CPL; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        s1 += xr[i].v[j];
-                        s2 = fmaf(xr[i].v[j], xr[i].v[j], s2);
-                    }
-                s1 = group_allsum<LPR>(s1);
-                s2 = group_allsum<LPR>(s2);
-                const float n = (float)K;
-                const float mean = s1 / n;
-                const float rstd = 1.0f / sqrtf(s2 / n - mean * mean + a.eps);
-#pragma unroll
-                for (int i = 0; i < CPL; ++i) {
-                    const int c = lr + LPR * i;
-                    if (c < nch) {
-                        const W8 g = load_x8(a.ln_g + c * 8), b = load_x8(a.ln_b + c * 8);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            xr[i].v[j] = fmaf((xr[i].v[j] - mean) * rstd, g.v[j], b.v[j]);
-                    }
+            for (int m = 0; m < MT; ++m)
+                for (int i = tid; i < nq; i += 256) {
+                    f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (m < M) o = reinterpret_cast<const f32x4*>(xin + (size_t)m * a.x_stride)[i];
+                    reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = o;
                 }
-            }
-        }
-    } else {
-        // LDS path: xs[m][k] for all MT rows; wave w prepares rows w, w+4, ...
-        for (int m = wave; m < MT; m += 4) {
-            float* xs = smem + (size_t)m * K;
-            if (m >= a.M) {
-                for (int k = lane; k < K; k += 64) xs[k] = 0.0f;
-                continue;
-            }
-            if (a.prologue == PRO_ATTN_MERGE) {
-                const int nsplit = (T + kAttnChunk - 1) / kAttnChunk;
-                for (int c = lane; c < nch; c += 64) {
-                    const W8 o = merge_attn8(a, m, c * 8, nsplit);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) xs[c * 8 + j] = o.v[j];
-                }
-            } else {
-                const float* x = a.x + (size_t)m * a.x_stride;
-                float s1 = 0.0f, s2 = 0.0f;
-                for (int k = lane; k < K; k += 64) {
-                    const float v = x[k];
-                    xs[k] = v;
-                    s1 += v;
-                    s2 = fmaf(v, v, s2);
-                }
-                if (a.prologue == PRO_LAYERNORM) {
-                    s1 = wave_allsum(s1);
-                    s2 = wave_allsum(s2);
-                    const float n = (float)K;
-                    const float mean = s1 / n;
-                    const float rstd = 1.0f / sqrtf(s2 / n - mean * mean + a.eps);
-                    for (int k = lane; k < K; k += 64)
-                        xs[k] = fmaf((xs[k] - mean) * rstd, a.ln_g[k], a.ln_b[k]);
-                }
-            }
         }
         __syncthreads();
     }
+    ZG_STAMP(3);
 
-    // ---------------------------------------------------------------- rows
+    W8 xr[XREG ? CPL : 1];
+    if constexpr (XREG) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lr + LPR * i;
+            xr[i] = (c < nch) ? load_x8(xs + c * 8) : zero_w8();
+        }
+    }
+    ZG_STAMP(4);
+
+    // ---- 2. rows, software-pipelined one pass (RPP rows) deep
     Best best[ARGMAX ? MT : 1];
 #pragma unroll
     for (int m = 0; m < (ARGMAX ? MT : 1); ++m) {
         best[m].val = -3.0e38f;
         best[m].idx = 0x7fffffff;
     }
+    const int pos = T - 1;
 
-    for (int rb = row_begin; rb < row_end; rb += 2 * RPP) {
-        const int r0 = rb + rsub, r1 = rb + RPP + rsub;
-        const bool v0 = r0 < row_end, v1 = r1 < row_end;
-        const WT* w0p = W + (size_t)(v0 ? r0 : row_begin) * K;
-        const WT* w1p = W + (size_t)(v1 ? r1 : row_begin) * K;
-        Raw<WT> w0[CPL], w1[CPL];
+    auto do_pass = [&](const Raw<WT>(&w)[CPL], const RowExtra<MT>& ex, int r, bool valid) {
+        float acc[MT];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = lr + LPR * i;
-            if (c < nch) {
-                w0[i] = load_raw(w0p, c);
-                w1[i] = load_raw(w1p, c);
-            } else {
-                zero_raw(w0[i]);
-                zero_raw(w1[i]);
-            }
-        }
-        float acc0[MT], acc1[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc0[m] = acc1[m] = 0.0f;
+        for (int m = 0; m < MT; ++m) acc[m] = 0.0f;
         if constexpr (XREG) {
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                acc0[0] = dot8(unpack(w0[i]), xr[i], acc0[0]);
-                acc1[0] = dot8(unpack(w1[i]), xr[i], acc1[0]);
-            }
+            for (int i = 0; i < CPL; ++i) acc[0] = dot8(unpack(w[i]), xr[i], acc[0]);
         } else {
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 const int c = lr + LPR * i;
                 if (c < nch) {
-                    const W8 u0 = unpack(w0[i]), u1 = unpack(w1[i]);
+                    const W8 u = unpack(w[i]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const W8 x = load_x8(smem + (size_t)m * K + c * 8);
-                        acc0[m] = dot8(u0, x, acc0[m]);
-                        acc1[m] = dot8(u1, x, acc1[m]);
-                    }
+                    for (int m = 0; m < MT; ++m) acc[m] = dot8(u, load_x8(xs + (size_t)m * K + c * 8), acc[m]);
                 }
             }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            acc0[m] = group_allsum<LPR>(acc0[m]);
-            acc1[m] = group_allsum<LPR>(acc1[m]);
-        }
-        if (lr == 0) {
+        for (int m = 0; m < MT; ++m) acc[m] = group_allsum<LPR>(acc[m]);
+        if (lr == 0 && valid) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (m < a.M) {
-                    if (v0) epilogue_row(a, m, r0, acc0[m], pos, best[ARGMAX ? m : 0]);
-                    if (v1) epilogue_row(a, m, r1, acc1[m], pos, best[ARGMAX ? m : 0]);
-                }
-            }
+            for (int m = 0; m < MT; ++m)
+                if (m < M) epilogue_row(a, m, r, acc[m], ex.bias, ex.resid[m], pos, best[ARGMAX ? m : 0]);
         }
+    };
+
+    for (int rb = row_begin; rb < row_end; rb += 2 * RPP) {
+        const int r0 = rb + rsub, r1 = rb + RPP + rsub, r2 = rb + 2 * RPP + rsub;
+        load_pass<WT, LPR, CPL>(wb, W, K, nch, r1, N, lr);
+        eb = load_extra<MT>(a, epilogue, M, N, r1);
+        do_pass(wa, ea, r0, r0 < row_end);
+        ZG_STAMP(5);
+        load_pass<WT, LPR, CPL>(wa, W, K, nch, r2, N, lr);
+        ea = load_extra<MT>(a, epilogue, M, N, r2);
+        do_pass(wb, eb, r1, r1 < row_end);
+        ZG_STAMP(6);
     }
 
-    // ---------------------------------------------------------------- argmax partials
+    ZG_STAMP(7);
+    ZG_STAMP_FLUSH();
+    // ---- 3. argmax partials
     if constexpr (ARGMAX) {
-        __shared__ float s_val[4 * 8];
-        __shared__ int s_idx[4 * 8];
+        __syncthreads();  // the per-wave strips may still be read by slower waves
+        float* s_val = red;
+        int* s_idx = reinterpret_cast<int*>(red + 4 * 8);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const Best b = wave_best(best[m]);
@@ -351,8 +519,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
             }
         }
         __syncthreads();
-        if (threadIdx.x < MT && (int)threadIdx.x < a.M) {
-            const int m = threadIdx.x;
+        if (tid < MT && tid < M) {
+            const int m = tid;
             Best b;
             b.val = s_val[m];
             b.idx = s_idx[m];
@@ -391,7 +559,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const GemvArgs a) {
 
 template <typename WT, int MT, int LPR, int CPL, bool ARGMAX>
 int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
-    const size_t lds = (MT == 1 && CPL <= 8) ? 0 : (size_t)MT * a.K * sizeof(float);
+    const size_t lds = ((size_t)(MT == 1 ? 4 : MT) * a.K + 4 * MT * 2 + 64) * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised = false;  // opt in once per instantiation to >64 KiB dynamic LDS
         if (!raised) {
@@ -401,7 +569,8 @@ int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
         }
     }
     ZG_REQUIRE(lds <= 160 * 1024, ZG_ERR_UNSUPPORTED, "gemv: M=%d x K=%d does not fit LDS", a.M, a.K);
-    hipLaunchKernelGGL((gemv_kernel<WT, MT, LPR, CPL, ARGMAX>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemv_kernel<WT, MT, LPR, CPL, ARGMAX>), dim3(grid), dim3(256), lds, s, a.W, a.x, a.N, a.K,
+                       a.M, a.rows_per_wave, a.prologue, a.epilogue, a.ln_g, a.ln_b, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -38,6 +38,7 @@ struct GemvArgs {
     const float* part;
     int n_heads, head_dim, max_splits;
     const StepCtrl* ctrl;  // seq_len for the merge / KV scatter position
+    int t_hi;  // launch-time upper bound of seq_len (same 256-position chunk as seq_len); 0 = read ctrl
     // EPI_STORE / EPI_RESIDUAL / EPI_GELU
     float* y;
     int y_stride;
@@ -54,6 +55,8 @@ struct GemvArgs {
     int logits_stride;
     float* part_val;
     int* part_idx;
+    const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
+    unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
 };
 
 // Fills rows_per_wave and returns the grid size for the given problem.
@@ -70,6 +73,7 @@ struct AttnArgs {
     int n_heads, head_dim, batch;
     const StepCtrl* ctrl;  // seq_len read from ctrl->seq_len when non-null
     int seq_len;           // used when ctrl == nullptr
+    int t_hi;              // launch-time upper bound of seq_len in the same 64-position bucket (>= seq_len)
     int max_splits;
     float* part;  // [B][H][max_splits][kPartStride]
 };
@@ -107,6 +111,7 @@ struct EmbedArgs {
     const float* part_val;   // [B][n_partials]
     const int* part_idx;
     int part_stride;
+    int n_partials;          // lm_head grid size
     float* x;                // [B][E]
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
 };

@@ -20,9 +20,11 @@ struct Ctx {
     size_t stage_cap = 0;
     size_t stage_off = 0;
     int* d_flag = nullptr;         // device int used for index-range checks
+    float* d_zero = nullptr;       // 64 zero bytes (stand-in operand for absent bias / residual)
     float* attn_part = nullptr;    // op-tier attention partials (sized at init)
     size_t attn_part_floats = 0;
     std::unordered_map<const void*, Registered> registry;
+    unsigned long long* dbg = nullptr;  // -DZG_STAMPS diagnostic buffer
 };
 
 Ctx& ctx();
