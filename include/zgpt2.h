@@ -114,6 +114,16 @@ int zg_gelu(float* inputs, size_t inputs_len);
 /* softmax — src/ops.zig:231-241, in place; the whole slice is one vector. */
 int zg_softmax(float* inputs, size_t inputs_len);
 
+/* Batched-regime Linear on the matrix cores (MFMA): C[M,N] = A[M,K] * B[N,K]^T (+ bias) with an
+ * optional fused GELU — the same contraction as Linear.forward's cblas_sgemm(NoTrans, Trans)
+ * (src/ops.zig:30-45) for large batch (prefill), with both operands in ops.Linear's K-contiguous
+ * layouts.  A, B are bf16 bit patterns and C is bf16 (out_bf16 != 0) or fp32, all DEVICE pointers;
+ * M, N multiples of 128, K multiple of 64.  Asynchronous on the library stream.
+ * zg_f32_to_bf16 converts a device or host fp32 array into a device bf16 array (round to nearest even). */
+int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_null, void* C, size_t M,
+                    size_t N, size_t K, int gelu, int out_bf16);
+int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len);
+
 /* ------------------------------------------------------------------ model tier: src/main.zig */
 
 /* GPTConfig — src/main.zig:5-23, field for field. */

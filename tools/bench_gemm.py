@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""MFMA utilisation of the 768x3072 (c_fc) GEMM: C[M,3072] = A[M,768] * W[3072,768]^T + bias, GELU, bf16 out.
+Reports TFLOP/s against the 2.5 PFLOP/s dense bf16 peak for M in {1024, 8192} (BASELINE headline M = 8192)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from zig_gpt2_amd import _lib, synth
+
+PEAK_TF = 2500.0
+
+
+def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
+    a = torch.from_numpy(synth.to_bf16_bits(synth.fill_uniform(1, m * k, -1, 1)).view(np.int16)).cuda()
+    b = torch.from_numpy(synth.to_bf16_bits(synth.fill_normal(2, n * k, 0, 0.02)).view(np.int16)).cuda()
+    bias = torch.from_numpy(synth.fill_normal(3, n, 0, 0.02)).cuda()
+    c = torch.empty((m, n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    _lib.check(lib.zg_set_stream(stream.cuda_stream))
+    run = lambda: _lib.check(lib.zg_gemm_bf16_nt(a.data_ptr(), b.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, int(gelu), int(out_bf16)))
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flops = 2.0 * m * n * k
+    return {"M": m, "N": n, "K": k, "us": round(us, 2), "tflops": round(flops / us / 1e6, 1),
+            "mfma_frac_of_2.5PF": round(flops / us / 1e6 / PEAK_TF, 4), "gelu": gelu, "out": "bf16" if out_bf16 else "f32",
+            "bytes_min": (m * k + n * k) * 2 + m * n * (2 if out_bf16 else 4)}
+
+
+if __name__ == "__main__":
+    lib = _lib.load(); _lib.check(lib.zg_init(0))
+    for m in (1024, 8192):
+        print(json.dumps(measure(lib, m)))
+    print(json.dumps(measure(lib, 8192, gelu=False, out_bf16=False)))
+    print(json.dumps(measure(lib, 8192, n=4096, k=4096, gelu=False)))

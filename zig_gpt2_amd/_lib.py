@@ -49,6 +49,8 @@ SIGNATURES = {
     "zg_split_qkv": (C.c_int, [sz, sz, vp, sz, sz, vp, sz]),
     "zg_transpose": (C.c_int, [sz, sz, sz, vp, sz, vp, sz]),
     "zg_scaled_dot_product_attention": (C.c_int, [vp, sz, vp, sz, vp, sz, sz, sz, sz, vp, sz, vp, sz]),
+    "zg_gemm_bf16_nt": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, C.c_int, C.c_int]),
+    "zg_f32_to_bf16": (C.c_int, [vp, vp, sz]),
     "zg_gelu": (C.c_int, [vp, sz]),
     "zg_softmax": (C.c_int, [vp, sz]),
     "zg_gpt_create": (C.c_int, [C.POINTER(vp), C.POINTER(GptConfig), sz, C.c_uint]),

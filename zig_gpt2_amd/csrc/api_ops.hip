@@ -300,6 +300,31 @@ int zg_linear_forward(size_t in_features, size_t out_features, const float* weig
     return ZG_OK;
 }
 
+// ------------------------------------------------------------------------------ MFMA GEMM
+int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_null, void* C, size_t M, size_t N,
+                    size_t K, int gelu, int out_bf16) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(A && B && C, ZG_ERR_ARG, "gemm_bf16_nt: null argument");
+    ZG_REQUIRE(is_device_ptr(A) && is_device_ptr(B) && is_device_ptr(C) && (!bias_or_null || is_device_ptr(bias_or_null)),
+               ZG_ERR_ARG, "gemm_bf16_nt: operands must be device pointers");
+    ZG_REQUIRE(M < (1u << 30) && N < (1u << 30) && K < (1u << 30), ZG_ERR_SHAPE, "gemm_bf16_nt: dimension too large");
+    return launch_gemm_bf16_nt(A, B, bias_or_null, C, (int)M, (int)N, (int)K, (int)N, gelu != 0, out_bf16 != 0,
+                               ctx().stream);
+}
+
+int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(src && dst_device && is_device_ptr(dst_device), ZG_ERR_ARG, "f32_to_bf16: bad argument");
+    Call call;
+    CallGuard guard(call);
+    const float* s;
+    ZG_TRY(call.in(src, len, &s));
+    ZG_TRY(launch_f32_to_bf16(s, dst_device, len, call.stream()));
+    ZG_TRY(call.finish());
+    guard.done = true;
+    return ZG_OK;
+}
+
 // ------------------------------------------------------------------------------ Embedding
 int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len, const size_t* idxs,
                          size_t idxs_len, float* embeddings, size_t embeddings_len) {

@@ -93,6 +93,11 @@ int launch_transpose(const float* in, size_t batch, size_t t, size_t n, size_t h
 int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 
+// ------------------------------------------------------------------------------------ MFMA GEMM
+// C[M,N] = A[M,K] * B[N,K]^T (+ bias) (optional GELU); bf16 operands, fp32 accumulate; C bf16 or fp32.
+int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                        bool gelu, bool out_bf16, hipStream_t s);
+
 // Decode-step head kernel: token selection (+ argmax finalisation of the previous step) and
 // x = wte[token] + wpe[pos].
 struct EmbedArgs {
