@@ -1,0 +1,239 @@
+// zgpt2_main.cpp — C++ restatement of the reference's host program (src/main.zig) on top of the
+// drop-in boundary: GPTConfig / State / MLP / Block / GPT / generate are written against
+// ops::{Linear, Embedding, LayerNorm, CausalSelfAttention, gelu} (include/zgpt2_ops.hpp) exactly the
+// way main.zig is written against ops.zig — one op call at a time with host buffers the caller
+// allocated once — and, with --model-tier, against the device-resident zg_gpt_* tier (one FFI call
+// per generation).  There are no GPT-2 checkpoints or vocab files offline, so weights come from the
+// portable synthetic generator (bit-identical to zig_gpt2_amd/synth.py), the prompt is a list of
+// token ids, and sampling is greedy argmax instead of the reference's time-seeded multinomial.
+//
+//   zgpt2_main <tiny|tiny3|nano-char|124M> <weight_seed> <tok,tok,...> <n_steps> [--model-tier]
+// prints the tokens after every step on one line (prompt tokens included, main.zig:339-340).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/zgpt2_ops.hpp"
+
+using ops::Slice;
+typedef std::vector<float> Buf;
+
+// ---------------------------------------------------------------- synthetic weights (synth.py twin)
+static inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static Buf fill_normal(uint64_t seed, size_t n, float mean, float std_) {
+    const uint64_t key = mix64(seed + 0x9E3779B97F4A7C15ULL);
+    const float scale = (float)((double)std_ / 37837.22753904532);
+    Buf out(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t r = mix64(key + (i + 1) * 0x9E3779B97F4A7C15ULL);
+        const int32_t s = (int32_t)(r & 0xFFFF) + (int32_t)((r >> 16) & 0xFFFF) + (int32_t)((r >> 32) & 0xFFFF) +
+                          (int32_t)((r >> 48) & 0xFFFF) - 131070;
+        float v = (float)s * scale;
+        v = v + mean;
+        uint32_t b;
+        memcpy(&b, &v, 4);
+        b += 0x7FFFu + ((b >> 16) & 1u);  // round to bf16 (RNE) so fp32 and bf16 storage agree
+        b &= 0xFFFF0000u;
+        memcpy(&v, &b, 4);
+        out[i] = v;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------- src/main.zig:5-23
+struct GPTConfig {
+    size_t vocab_size, context_size, n_layer, n_heads, n_embed;
+};
+
+// ---------------------------------------------------------------- src/main.zig:26-65
+struct State {
+    Buf pos_emb, x, o, logits, _h, _4xh, _qkv, _q, _k, _v, _attn;
+    explicit State(const GPTConfig& c)
+        : pos_emb(c.n_embed), x(c.n_embed), o(c.n_embed), logits(c.vocab_size), _h(c.n_embed), _4xh(4 * c.n_embed),
+          _qkv(3 * c.n_embed), _q(c.n_embed), _k(c.context_size * c.n_embed), _v(c.context_size * c.n_embed),
+          _attn(c.context_size) {}
+};
+
+struct Weights {  // tensor order / seeds of zig_gpt2_amd/synth.py::tensor_specs
+    Buf wte, wpe, ln_f_g, ln_f_b;
+    struct Layer {
+        Buf t[12];
+    };
+    std::vector<Layer> h;
+    Weights(const GPTConfig& c, uint64_t seed) {
+        const size_t E = c.n_embed;
+        wte = fill_normal(seed * 4096 + 0, c.vocab_size * E, 0.f, 0.02f);
+        wpe = fill_normal(seed * 4096 + 1, c.context_size * E, 0.f, 0.02f);
+        ln_f_g = fill_normal(seed * 4096 + 2, E, 1.f, 0.02f);
+        ln_f_b = fill_normal(seed * 4096 + 3, E, 0.f, 0.02f);
+        const size_t sizes[12] = {E, E, 3 * E * E, 3 * E, E * E, E, E, E, 4 * E * E, 4 * E, 4 * E * E, E};
+        const float means[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        h.resize(c.n_layer);
+        for (size_t l = 0; l < c.n_layer; ++l)
+            for (int s = 0; s < 12; ++s) h[l].t[s] = fill_normal(seed * 4096 + 16 + 16 * l + s, sizes[s], means[s], 0.02f);
+    }
+};
+
+// ---------------------------------------------------------------- src/main.zig:67-83
+struct MLP {
+    ops::Linear c_fc, c_proj;
+    void forward(Slice<const float> inputs, State& state) const {
+        c_fc.forward(inputs, state._4xh);
+        ops::gelu(state._4xh);
+        c_proj.forward(Slice<const float>(state._4xh.data(), state._4xh.size()), state.o);
+    }
+};
+
+// ---------------------------------------------------------------- src/main.zig:85-147
+struct Block {
+    size_t n_embed;
+    ops::LayerNorm ln_1;
+    ops::CausalSelfAttention attn;
+    ops::LayerNorm ln_2;
+    MLP mlp;
+    Buf k_cache, v_cache;
+    void forward(size_t seq_len, State& state) {  // inputs == state.x, as main.zig:187 passes it
+        const size_t E = n_embed;
+        state._h = state.x;
+        ln_1.forward(state._h);
+        attn.forward(seq_len, Slice<const float>(state._h.data(), E), Slice<float>(k_cache.data(), seq_len * E),
+                     Slice<float>(v_cache.data(), seq_len * E), state.o, state._qkv, state._q,
+                     Slice<float>(state._k.data(), seq_len * E), Slice<float>(state._v.data(), seq_len * E),
+                     Slice<float>(state._attn.data(), seq_len));
+        for (size_t i = 0; i < E; ++i) {  // main.zig:136-139
+            state._h[i] = state.o[i] + state.x[i];
+            state.x[i] = state._h[i];
+        }
+        ln_2.forward(state._h);
+        mlp.forward(Slice<const float>(state._h.data(), E), state);
+        for (size_t i = 0; i < E; ++i) {  // main.zig:142-145
+            state.o[i] += state.x[i];
+            state.x[i] = state.o[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------- src/main.zig:149-208
+struct GPT {
+    GPTConfig config;
+    ops::Embedding wte, wpe;
+    std::vector<Block> h;
+    ops::LayerNorm ln_f;
+    ops::Linear lm_head;
+
+    GPT(const GPTConfig& c, const Weights& w) : config(c) {  // load_gpt, main.zig:304-314
+        const size_t E = c.n_embed;
+        auto S = [](const Buf& b) { return Slice<const float>(b.data(), b.size()); };
+        wte = ops::Embedding::init(E, S(w.wte));
+        wpe = ops::Embedding::init(E, S(w.wpe));
+        ln_f = ops::LayerNorm::init(E, S(w.ln_f_g), S(w.ln_f_b));
+        lm_head = ops::Linear::init(E, c.vocab_size, S(w.wte), Slice<const float>());  // main.zig:312
+        for (size_t l = 0; l < c.n_layer; ++l) {
+            const Buf* t = w.h[l].t;
+            Block b;
+            b.n_embed = E;
+            b.ln_1 = ops::LayerNorm::init(E, S(t[0]), S(t[1]));
+            b.attn = ops::CausalSelfAttention::init(c.n_heads, E, ops::Linear::init(E, 3 * E, S(t[2]), S(t[3])),
+                                                    ops::Linear::init(E, E, S(t[4]), S(t[5])));
+            b.ln_2 = ops::LayerNorm::init(E, S(t[6]), S(t[7]));
+            b.mlp = MLP{ops::Linear::init(E, 4 * E, S(t[8]), S(t[9])), ops::Linear::init(4 * E, E, S(t[10]), S(t[11]))};
+            b.k_cache.assign(c.context_size * E, 0.f);  // main.zig:298-299
+            b.v_cache.assign(c.context_size * E, 0.f);
+            h.push_back(std::move(b));
+        }
+    }
+
+    void forward(size_t seq_len, size_t token, bool compute_logits, State& state) {  // main.zig:178-195
+        const size_t pos = seq_len - 1;
+        wpe.forward(Slice<const size_t>(&pos, 1), state.pos_emb);
+        wte.forward(Slice<const size_t>(&token, 1), state.x);
+        for (size_t i = 0; i < config.n_embed; ++i) state.x[i] += state.pos_emb[i];
+        for (auto& blk : h) blk.forward(seq_len, state);
+        ln_f.forward(state.x);
+        if (compute_logits) lm_head.forward(Slice<const float>(state.x.data(), state.x.size()), state.logits);
+    }
+
+    size_t sample_greedy(size_t seq_len, size_t token, State& state) {  // replaces main.zig:198-207
+        forward(seq_len, token, true, state);
+        size_t best = 0;
+        for (size_t i = 1; i < state.logits.size(); ++i)
+            if (state.logits[i] > state.logits[best]) best = i;
+        return best;
+    }
+};
+
+// ---------------------------------------------------------------- src/main.zig:322-342 (greedy)
+static std::vector<size_t> generate(GPT& gpt, const std::vector<size_t>& inputs, size_t n_steps, State& state) {
+    std::vector<size_t> out;
+    size_t token = 0;
+    for (size_t s = 0; s < n_steps; ++s) {
+        if (s < inputs.size()) {
+            token = inputs[s];
+            gpt.forward(s + 1, token, false, state);
+        } else {
+            token = gpt.sample_greedy(s + 1, token, state);
+        }
+        out.push_back(token);
+    }
+    return out;
+}
+
+static std::vector<size_t> generate_model_tier(const GPTConfig& c, const Weights& w, const std::vector<size_t>& inputs,
+                                               size_t n_steps) {
+    zg_gpt_config cfg{c.vocab_size, c.context_size, c.n_layer, c.n_heads, c.n_embed};
+    zg_gpt* g = nullptr;
+    ops::check(zg_gpt_create(&g, &cfg, 1, ZG_GPT_WEIGHTS_BF16));
+    const Buf* top[4] = {&w.wte, &w.wpe, &w.ln_f_g, &w.ln_f_b};
+    for (int s = 0; s < 4; ++s) ops::check(zg_gpt_load_tensor(g, s, top[s]->data(), top[s]->size()));
+    for (size_t l = 0; l < c.n_layer; ++l)
+        for (int s = 0; s < 12; ++s) ops::check(zg_gpt_load_block_tensor(g, l, s, w.h[l].t[s].data(), w.h[l].t[s].size()));
+    std::vector<size_t> out(n_steps);
+    const size_t len = inputs.size();
+    ops::check(zg_gpt_generate_greedy(g, inputs.data(), inputs.size(), &len, n_steps, out.data(), out.size()));
+    zg_gpt_destroy(g);
+    return out;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 5) {
+        fprintf(stderr, "usage: %s <tiny|tiny3|nano-char|124M> <seed> <tok,tok,...> <n_steps> [--model-tier]\n", argv[0]);
+        return 2;
+    }
+    const std::string name = argv[1];
+    GPTConfig config;
+    if (name == "tiny") config = {257, 64, 2, 2, 128};
+    else if (name == "tiny3") config = {131, 48, 3, 3, 192};
+    else if (name == "nano-char") config = {65, 256, 6, 6, 384};
+    else if (name == "124M") config = {50257, 1024, 12, 12, 768};  // main.zig:346
+    else return 2;
+    const uint64_t seed = strtoull(argv[2], nullptr, 10);
+    std::vector<size_t> inputs;
+    for (char* p = strtok(argv[3], ","); p; p = strtok(nullptr, ",")) inputs.push_back(strtoull(p, nullptr, 10));
+    const size_t n_steps = strtoull(argv[4], nullptr, 10);
+    const bool model_tier = argc > 5 && std::string(argv[5]) == "--model-tier";
+    try {
+        ops::check(zg_init(0));
+        Weights w(config, seed);
+        std::vector<size_t> out;
+        if (model_tier) {
+            out = generate_model_tier(config, w, inputs, n_steps);
+        } else {
+            State state(config);
+            GPT gpt(config, w);
+            out = generate(gpt, inputs, n_steps, state);
+        }
+        for (size_t i = 0; i < out.size(); ++i) printf("%zu%s", out[i], i + 1 < out.size() ? " " : "\n");
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
