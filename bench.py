@@ -56,11 +56,7 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
     1..ctx run is priced from the two windows."""
     import oracle
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = oracle.host_cores()  # affinity mask clipped by the cgroup CPU quota: the threads actually usable
     oracle.set_num_threads(cores)
     blas = "built-in OpenMP sgemm"
     found = oracle.find_cblas()
@@ -83,8 +79,8 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
             blas = found[2]
         else:
             oracle.use_cblas(None)
-    n_win = max(4, int(budget_s / 2 / max(t_builtin, 1e-3) / 1.5))
-    n_win = min(n_win, 64)
+    n_win = max(8, int(budget_s / 2 / max(min(t_builtin, 1.0), 1e-3) / 1.5))
+    n_win = min(n_win, 96)
     lo0, hi0 = 1, max(1, ctx - n_win)
     t_lo = window(lo0, n_win)
     t_hi = window(hi0, n_win)
@@ -109,7 +105,7 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     import torch
 
-    from zig_gpt2_amd import _lib, gpt, synth
+    from zig_gpt2_amd import _lib, gpt, shard, synth
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
@@ -143,13 +139,14 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.perf_counter()
-        dist.broadcast(arena, src=0)
+        shard.broadcast_weights(arena, dist, src=0)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - tb) * 1e3
     setup_s = time.perf_counter() - t0
 
     # ---- prompts: one token each, distinct per global prompt index
-    prompts = [synth.rand_tokens(1000 + a.seed * 131 + rank * ppg + b, 1, cfg.vocab_size) for b in range(ppg)]
+    mine = shard.shard_prompts(ppg * world, world, rank)
+    prompts = [synth.rand_tokens(1000 + a.seed * 131 + gi, 1, cfg.vocab_size) for gi in mine]
 
     def one_generation():
         model.generate_enqueue(prompts, ctx)
@@ -196,8 +193,28 @@ def main():
     prof_hi = model.profile_step(ctx - n_prof + 1, n_prof)
     lm_us = 0.5 * (prof_lo["lnf_lm_head_argmax"] + prof_hi["lnf_lm_head_argmax"])
     lm_bytes = cfg.vocab_size * cfg.n_embed * (4 if a.weights_f32 else 2) * 1.0
-    lm_loop_us, _ = model.time_kernel(_lib.TIME_LM_HEAD, 200)
+    lm_loop_us, _ = model.time_kernel(_lib.TIME_LM_HEAD, 256)
     achieved = lm_bytes / (lm_us * 1e-6) / 1e9
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): bench.py itself cannot collect counters.
+    traffic, rocprof_us = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "lm_head_traffic.json")) as f:
+            tj = json.load(f)
+        if a.model == "124M" and ppg == 1 and not a.weights_f32:
+            traffic, rocprof_us = tj["traffic_bytes_per_launch"], tj["rocprof_avg_us"]
+    except Exception:
+        pass
+    gemm = None
+    if a.model == "124M" and world == 1:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_gemm
+
+            gemm = bench_gemm.measure(lib, 8192)
+            _lib.check(lib.zg_set_stream(stream.cuda_stream))
+        except Exception as e:  # the headline metric must not die with the secondary one
+            gemm = {"error": str(e)}
     # whole-step view: algorithmic bytes of all ctx steps / device time
     kv_elem = 2 if a.kv_f16 else 4
     kv_total = sum(kv_elem * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
@@ -227,11 +244,12 @@ def main():
         "roofline": {
             "kernel": "gemv_kernel<bf16,M=%d,LPR16,CPL6,ARGMAX> (ln_f + lm_head + argmax)" % (1 if ppg == 1 else (2 if ppg == 2 else (4 if ppg <= 4 else 8))),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(lm_bytes), "avg_launch_us": round(lm_us, 2),
-            "avg_launch_us_back_to_back_loop": round(lm_loop_us, 2),
-            "how": f"HIP events around the kernel in {2 * n_prof} eager decode steps (T=1.. and T={ctx - n_prof + 1}..) "
-                   "on the launch stream, right after the timed region",
+            "avg_launch_us_warm_graph_chain": round(lm_loop_us, 2), "rocprof_avg_us_committed_profile": rocprof_us,
+            "how": f"HIP events on the launch stream around the kernel inside {2 * n_prof} complete decode steps "
+                   f"(T=1.. and T={ctx - n_prof + 1}..) enqueued back to back right after the timed region; the "
+                   "event-to-event interval includes the ~1.6 us launch boundary, so `achieved` is a lower bound",
         },
         "step_roofline": {
             "bound": "hbm", "algorithmic_bytes_per_generation": int(step_bytes_total),
@@ -241,6 +259,7 @@ def main():
             "per_kernel_class_us_eager_T_low": {k: round(v, 2) for k, v in prof_lo.items()},
             "per_kernel_class_us_eager_T_high": {k: round(v, 2) for k, v in prof_hi.items()},
         },
+        "mfma_gemm_768x3072": gemm,
         "device_time_s": round(dev_s, 4),
         "setup_s": round(setup_s, 2),
         "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),

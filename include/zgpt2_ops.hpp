@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 #include "zgpt2.h"
 
@@ -19,7 +20,7 @@ struct Slice {
     size_t len = 0;
     Slice() = default;
     Slice(T* p, size_t n) : ptr(p), len(n) {}
-    template <typename C>
+    template <typename C, typename = decltype(std::declval<C&>().data())>
     Slice(C& c) : ptr(c.data()), len(c.size()) {}  // NOLINT: std::vector / std::array
     Slice sub(size_t begin, size_t end) const { return Slice(ptr + begin, end - begin); }
     operator Slice<const T>() const { return Slice<const T>(ptr, len); }
