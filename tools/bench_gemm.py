@@ -35,7 +35,11 @@ def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
 
 if __name__ == "__main__":
     lib = _lib.load(); _lib.check(lib.zg_init(0))
-    for m in (1024, 8192):
+    if len(sys.argv) > 1:  # e.g. `bench_gemm.py 8192` or `bench_gemm.py 8192 4096 4096` (M N K)
+        a = [int(v) for v in sys.argv[1:]]
+        print(json.dumps(measure(lib, a[0], *(a[1:3] if len(a) >= 3 else ()))))
+        sys.exit(0)
+    for m in (1024, 8192, 16384):
         print(json.dumps(measure(lib, m)))
     print(json.dumps(measure(lib, 8192, gelu=False, out_bf16=False)))
     print(json.dumps(measure(lib, 8192, n=4096, k=4096, gelu=False)))

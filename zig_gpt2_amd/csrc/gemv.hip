@@ -13,6 +13,8 @@
 //             EPI_GELU        ops.gelu                             (src/ops.zig:221-228)
 //             EPI_QKV         split_qkv + KV-cache append          (src/ops.zig:146-157)
 //             EPI_ARGMAX      greedy sampler partial argmax        (replaces src/main.zig:198-207)
+#include <stdlib.h>
+
 #include "zg_kernels.h"
 
 // Diagnostic build (-DZG_STAMPS): wave 0 of the first and of the last workgroup record s_memtime at
@@ -225,7 +227,7 @@ __device__ __forceinline__ f32x4 merge_attn4(const GemvArgs& a, int m, int e0, i
 template <typename WT, int LPR, int CPL>
 __device__ __forceinline__ void load_pass(Raw<WT> (&w)[CPL], const WT* W, int K, int nch, int row, int n_rows,
                                           int lr) {
-    const WT* wp = W + (size_t)min(row, n_rows - 1) * K;
+    const WT* wp = W + (size_t)max(min(row, n_rows - 1), 0) * K;  // n_rows = this wave's row_end: surplus slots re-read its own last row
 #pragma unroll
     for (int i = 0; i < CPL; ++i) w[i] = load_raw(wp, min(lr + LPR * i, nch - 1));
 }
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     RowExtra<MT> ea, eb;
     ZG_STAMP_DECL();
     ZG_STAMP(0);
-    load_pass<WT, LPR, CPL>(wa, W, K, nch, row_begin + rsub, N, lr);
+    load_pass<WT, LPR, CPL>(wa, W, K, nch, row_begin + rsub, row_end, lr);
     ea = load_extra<MT>(a, epilogue, M, N, row_begin + rsub);
 
     // position-dependent scalar (consumed late: merge split count when t_hi == 0, KV scatter position)
@@ -493,11 +495,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 
     for (int rb = row_begin; rb < row_end; rb += 2 * RPP) {
         const int r0 = rb + rsub, r1 = rb + RPP + rsub, r2 = rb + 2 * RPP + rsub;
-        load_pass<WT, LPR, CPL>(wb, W, K, nch, r1, N, lr);
+        load_pass<WT, LPR, CPL>(wb, W, K, nch, r1, row_end, lr);
         eb = load_extra<MT>(a, epilogue, M, N, r1);
         do_pass(wa, ea, r0, r0 < row_end);
         ZG_STAMP(5);
-        load_pass<WT, LPR, CPL>(wa, W, K, nch, r2, N, lr);
+        load_pass<WT, LPR, CPL>(wa, W, K, nch, r2, row_end, lr);
         ea = load_extra<MT>(a, epilogue, M, N, r2);
         do_pass(wb, eb, r1, r1 < row_end);
         ZG_STAMP(6);
@@ -633,6 +635,10 @@ int gemv_plan(GemvArgs& a) {
     int rpw = (a.N + target_waves - 1) / target_waves;
     rpw = ((rpw + rpp2 - 1) / rpp2) * rpp2;
     if (rpw < rpp2) rpw = rpp2;
+    if (const char* e = getenv("ZGPT2_RPW")) {  // tuning experiments only
+        const int v = atoi(e);
+        if (v > 0 && a.N > 20000) rpw = v;
+    }
     a.rows_per_wave = rpw;
     const int waves = (a.N + rpw - 1) / rpw;
     return (waves + 3) / 4;
