@@ -11,8 +11,9 @@ lib = _lib.load(); _lib.check(lib.zg_init(0))
 raw = C.CDLL(_lib.SO_PATH)
 raw.zg_debug_stamps_read.argtypes = [C.c_void_p, C.c_size_t]
 cfg = synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "124M"]
-m = gpt.GPT(cfg); m.load_weights(synth.make_weights(cfg, seed=0, bf16=True))
-m.generate([synth.rand_tokens(0, 1, cfg.vocab_size)], min(64, cfg.context_size))
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+m = gpt.GPT(cfg, batch=B); m.load_weights(synth.make_weights(cfg, seed=0, bf16=True))
+m.generate([synth.rand_tokens(b, 1, cfg.vocab_size) for b in range(B)], min(64, cfg.context_size))
 names = ["t0 entry", "t1 W issued+T", "t2 LN stats barrier", "t3 xs ready", "t4 xr in regs", "t5 pass A done", "t6 pass B done", "t7 loop end", "t9 flush"]
 for cls in (1, 3, 4, 5, 6):
     assert raw.zg_debug_stamps_begin() == 0

@@ -358,19 +358,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     } else {
         if (prologue == PRO_LAYERNORM && nq <= 512) {
             f32x4 v[MT][2], g4[2], b4[2];
+            // branch-free (clamped) loads: predicated ones serialise into one round trip each
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int i = tid + 256 * j;
-                if (i < nq) {
-                    g4[j] = reinterpret_cast<const f32x4*>(ln_g)[i];
-                    b4[j] = reinterpret_cast<const f32x4*>(ln_b)[i];
-                }
+                const int i = tid + 256 * j, ic = min(i, nq - 1);
+                g4[j] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+                b4[j] = reinterpret_cast<const f32x4*>(ln_b)[ic];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    v[m][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (i < nq && m < M) v[m][j] = reinterpret_cast<const f32x4*>(xin + (size_t)m * a.x_stride)[i];
-                }
+                for (int m = 0; m < MT; ++m)
+                    v[m][j] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[ic];
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if (tid + 256 * j >= nq || m >= M) v[m][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float t1 = 0.0f, t2 = 0.0f;
@@ -388,12 +390,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
             }
             __syncthreads();
             ZG_STAMP(2);
+            const float inv_k = 1.0f / (float)K;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const float s1 = red[m * 2] + red[(MT + m) * 2] + red[(2 * MT + m) * 2] + red[(3 * MT + m) * 2];
                 const float s2 = red[m * 2 + 1] + red[(MT + m) * 2 + 1] + red[(2 * MT + m) * 2 + 1] + red[(3 * MT + m) * 2 + 1];
-                const float mean = s1 / (float)K;
-                const float rstd = 1.0f / sqrtf(s2 / (float)K - mean * mean + a.eps);
+                const float mean = s1 * inv_k;
+                const float rstd = __builtin_amdgcn_rsqf(s2 * inv_k - mean * mean + a.eps);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int i = tid + 256 * j;
@@ -427,21 +430,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
         } else if (prologue == PRO_ATTN_MERGE) {
             const int t_hi = a.t_hi > 0 ? a.t_hi : T;
             const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
+            for (int i = tid; i < nq; i += 256) {
+                f32x4 o[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                for (int i = tid; i < nq; i += 256) {
-                    f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (m < M) o = merge_attn4(a, m, i * 4, nsplit);
-                    reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = o;
-                }
+                for (int m = 0; m < MT; ++m) o[m] = merge_attn4(a, min(m, M - 1), i * 4, nsplit);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = (m < M) ? o[m] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
         } else {
+            for (int i = tid; i < nq; i += 256) {
+                f32x4 o[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                for (int i = tid; i < nq; i += 256) {
-                    f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (m < M) o = reinterpret_cast<const f32x4*>(xin + (size_t)m * a.x_stride)[i];
-                    reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = o;
-                }
+                for (int m = 0; m < MT; ++m) o[m] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[i];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    reinterpret_cast<f32x4*>(xs + (size_t)m * K)[i] = (m < M) ? o[m] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
         }
         __syncthreads();
     }
@@ -471,8 +476,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = 0.0f;
         if constexpr (XREG) {
+            // four independent partial sums: a single accumulator is one 8*CPL-long dependent FMA chain,
+            // and with one wave per SIMD (small grids) nothing else hides the VALU latency
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) acc[0] = dot8(unpack(w[i]), xr[i], acc[0]);
+            for (int i = 0; i < CPL; ++i) {
+                const W8 u = unpack(w[i]);
+                p0 = fmaf(u.v[0], xr[i].v[0], p0); p1 = fmaf(u.v[1], xr[i].v[1], p1);
+                p2 = fmaf(u.v[2], xr[i].v[2], p2); p3 = fmaf(u.v[3], xr[i].v[3], p3);
+                p0 = fmaf(u.v[4], xr[i].v[4], p0); p1 = fmaf(u.v[5], xr[i].v[5], p1);
+                p2 = fmaf(u.v[6], xr[i].v[6], p2); p3 = fmaf(u.v[7], xr[i].v[7], p3);
+            }
+            acc[0] = (p0 + p1) + (p2 + p3);
         } else {
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
@@ -493,16 +508,61 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
         }
     };
 
-    for (int rb = row_begin; rb < row_end; rb += 2 * RPP) {
-        const int r0 = rb + rsub, r1 = rb + RPP + rsub, r2 = rb + 2 * RPP + rsub;
-        load_pass<WT, LPR, CPL>(wb, W, K, nch, r1, row_end, lr);
-        eb = load_extra<MT>(a, epilogue, M, N, r1);
-        do_pass(wa, ea, r0, r0 < row_end);
-        ZG_STAMP(5);
-        load_pass<WT, LPR, CPL>(wa, W, K, nch, r2, row_end, lr);
-        ea = load_extra<MT>(a, epilogue, M, N, r2);
-        do_pass(wb, eb, r1, r1 < row_end);
-        ZG_STAMP(6);
+    if constexpr (XREG) {
+        for (int rb = row_begin; rb < row_end; rb += 2 * RPP) {
+            const int r0 = rb + rsub, r1 = rb + RPP + rsub, r2 = rb + 2 * RPP + rsub;
+            load_pass<WT, LPR, CPL>(wb, W, K, nch, r1, row_end, lr);
+            eb = load_extra<MT>(a, epilogue, M, N, r1);
+            do_pass(wa, ea, r0, r0 < row_end);
+            ZG_STAMP(5);
+            load_pass<WT, LPR, CPL>(wa, W, K, nch, r2, row_end, lr);
+            ea = load_extra<MT>(a, epilogue, M, N, r2);
+            do_pass(wb, eb, r1, r1 < row_end);
+            ZG_STAMP(6);
+        }
+    } else {
+        // Batched / wide-K path: the input rows live in LDS, and LDS read bandwidth is what bounds it, so
+        // two weight rows share every input chunk that is read (halves the ds_read traffic per weight).
+        load_pass<WT, LPR, CPL>(wb, W, K, nch, row_begin + RPP + rsub, row_end, lr);
+        eb = load_extra<MT>(a, epilogue, M, N, row_begin + RPP + rsub);
+        for (int rb = row_begin; rb < row_end; rb += 2 * RPP) {
+            const int r0 = rb + rsub, r1 = rb + RPP + rsub;
+            float acc0[MT], acc1[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc0[m] = acc1[m] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int c = lr + LPR * i;
+                if (c < nch) {
+                    const W8 u0 = unpack(wa[i]), u1 = unpack(wb[i]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const W8 x = load_x8(xs + m * K + c * 8);
+                        acc0[m] = dot8(u0, x, acc0[m]);
+                        acc1[m] = dot8(u1, x, acc1[m]);
+                    }
+                }
+            }
+            const RowExtra<MT> e0 = ea, e1 = eb;
+            // next two rows' weights: requested before the reductions / epilogue of this pair
+            load_pass<WT, LPR, CPL>(wa, W, K, nch, r0 + 2 * RPP, row_end, lr);
+            ea = load_extra<MT>(a, epilogue, M, N, r0 + 2 * RPP);
+            load_pass<WT, LPR, CPL>(wb, W, K, nch, r1 + 2 * RPP, row_end, lr);
+            eb = load_extra<MT>(a, epilogue, M, N, r1 + 2 * RPP);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc0[m] = group_allsum<LPR>(acc0[m]);
+                acc1[m] = group_allsum<LPR>(acc1[m]);
+            }
+            if (lr == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if (m < M) {
+                        if (r0 < row_end) epilogue_row(a, m, r0, acc0[m], e0.bias, e0.resid[m], pos, best[ARGMAX ? m : 0]);
+                        if (r1 < row_end) epilogue_row(a, m, r1, acc1[m], e1.bias, e1.resid[m], pos, best[ARGMAX ? m : 0]);
+                    }
+            }
+        }
     }
 
     ZG_STAMP(7);

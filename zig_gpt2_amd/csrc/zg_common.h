@@ -65,12 +65,22 @@ __device__ __forceinline__ float row16_allsum(float v) {
     return v;
 }
 
+// Read one lane's value into a scalar register (v_readlane_b32): a few cycles, no LDS crossbar.
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+
 // Sum over groups of LPR consecutive lanes (LPR in {16, 32, 64}); all lanes get the total.
+// Rows are combined through v_readlane (scalar broadcast) rather than ds_bpermute: the LDS crossbar
+// costs ~100+ cycles of dependent latency per hop, which dominated the small latency-bound kernels.
 template <int LPR>
 __device__ __forceinline__ float group_allsum(float v) {
     v = row16_allsum(v);
-    if (LPR >= 32) v += __shfl_xor(v, 16, 64);
-    if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+    if (LPR == 32) {
+        const float lo = lane_value(v, 0) + lane_value(v, 16), hi = lane_value(v, 32) + lane_value(v, 48);
+        v = (threadIdx.x & 32) ? hi : lo;
+    }
+    if (LPR == 64) v = (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
     return v;
 }
 
@@ -81,9 +91,7 @@ __device__ __forceinline__ float wave_allmax(float v) {
     v = fmaxf(v, dpp_row_ror<4>(v));
     v = fmaxf(v, dpp_row_ror<2>(v));
     v = fmaxf(v, dpp_row_ror<1>(v));
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // gelu of src/ops.zig:221-228: 0.5 x (1 + tanh(u)), u = x * 0.7978845608 * (1 + 0.044715 x^2).
