@@ -145,3 +145,21 @@ def test_model_tier_errors(zg):
     with pytest.raises(_lib.ZgError):
         zgpt.GPT(synth.GPTConfig(100, 16, 1, 3, 96))  # head_dim 32
     m.close()
+
+
+def test_weights_from_reference_raw_directory(zg, tmp_path):
+    """Reference on-disk format (download_weights.py:57-64) -> model tier (fp32 storage) == oracle."""
+    from zig_gpt2_amd import weights_io
+
+    cfg = synth.CONFIGS["tiny"]
+    w = synth.make_weights(cfg, seed=51, bf16=False)
+    weights_io.save_raw_dir(tmp_path, cfg, w)
+    loaded = weights_io.load_raw_dir(tmp_path, cfg)
+    m = zgpt.GPT(cfg, weights_f32=True)
+    m.load_weights(loaded)
+    prompt = synth.rand_tokens(52, 2, cfg.vocab_size)
+    ids = m.generate([prompt], 32)[0]
+    ids_ref, lg = oracle.GPT(cfg, w).generate_greedy(prompt, 32, want_logits=True)
+    top = np.sort(lg, axis=1)
+    assert_greedy_ids_match(ids_ref[2:], ids[2:], top[:, -1], top[:, -2], "raw dir")
+    m.close()

@@ -249,6 +249,49 @@ __device__ __forceinline__ RowExtra<MT> load_extra(const GemvArgs& a, int epilog
     return e;
 }
 
+// LayerNorm of one input row by ONE wave into its private LDS strip (NJ float4 per lane cover the row).
+// Single pass sum / sum of squares; std = sqrt(E[x^2] - mean^2 + eps): reference src/ops.zig:88-101.
+// Loads are branch-free (index clamped, surplus zeroed afterwards) so they all fly together.
+template <int NJ>
+__device__ __forceinline__ void ln_strip(const float* __restrict__ xin, const float* __restrict__ ln_g,
+                                         const float* __restrict__ ln_b, f32x4* xw4, int nq, int K, float eps,
+                                         int lane) {
+    f32x4 v[NJ], g4[NJ], b4[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ic = min(lane + 64 * j, nq - 1);
+        v[j] = reinterpret_cast<const f32x4*>(xin)[ic];
+        g4[j] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+        b4[j] = reinterpret_cast<const f32x4*>(ln_b)[ic];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (lane + 64 * j >= nq) v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        t1 += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        t2 = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, t2))));
+    }
+    t1 = wave_allsum(t1);
+    t2 = wave_allsum(t2);
+    const float inv_k = 1.0f / (float)K;
+    const float mean = t1 * inv_k;
+    const float rstd = __builtin_amdgcn_rsqf(t2 * inv_k - mean * mean + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nq) {
+            f32x4 o;
+            o.x = fmaf((v[j].x - mean) * rstd, g4[j].x, b4[j].x);
+            o.y = fmaf((v[j].y - mean) * rstd, g4[j].y, b4[j].y);
+            o.z = fmaf((v[j].z - mean) * rstd, g4[j].z, b4[j].z);
+            o.w = fmaf((v[j].w - mean) * rstd, g4[j].w, b4[j].w);
+            xw4[i] = o;
+        }
+    }
+}
+
 // One workgroup = 4 waves; each wave owns rows [gw * rows_per_wave, +rows_per_wave).
 // LPR lanes share one row (RPP = 64 / LPR rows per pass); CPL 16-B chunks per lane per row.
 //
@@ -298,42 +341,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     // ---- 1. prologue: build the (transformed) input rows in LDS
     if constexpr (PERWAVE) {
         f32x4* xw4 = reinterpret_cast<f32x4*>(xs);
-        if (prologue == PRO_LAYERNORM && nq <= 256) {
-            f32x4 v[4], g4[4], b4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // branch-free: clamp the index, zero the surplus afterwards
-                const int i = lane + 64 * j, ic = min(i, nq - 1);
-                v[j] = reinterpret_cast<const f32x4*>(xin)[ic];
-                g4[j] = reinterpret_cast<const f32x4*>(ln_g)[ic];
-                b4[j] = reinterpret_cast<const f32x4*>(ln_b)[ic];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (lane + 64 * j >= nq) v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            // single pass sum / sum of squares; std = sqrt(E[x^2] - mean^2 + eps): ops.zig:88-95
-            float t1 = 0.0f, t2 = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t1 += v[j].x + v[j].y + v[j].z + v[j].w;
-                t2 = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, t2))));
-            }
-            t1 = wave_allsum(t1);
-            t2 = wave_allsum(t2);
+        if (prologue == PRO_LAYERNORM && nq <= 512) {
+            if (nq <= 192) ln_strip<3>(xin, ln_g, ln_b, xw4, nq, K, a.eps, lane);
+            else if (nq <= 256) ln_strip<4>(xin, ln_g, ln_b, xw4, nq, K, a.eps, lane);
+            else ln_strip<8>(xin, ln_g, ln_b, xw4, nq, K, a.eps, lane);
             ZG_STAMP(2);
-            const float mean = t1 / (float)K;
-            const float rstd = 1.0f / sqrtf(t2 / (float)K - mean * mean + a.eps);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = lane + 64 * j;
-                if (i < nq) {
-                    f32x4 o;
-                    o.x = fmaf((v[j].x - mean) * rstd, g4[j].x, b4[j].x);
-                    o.y = fmaf((v[j].y - mean) * rstd, g4[j].y, b4[j].y);
-                    o.z = fmaf((v[j].z - mean) * rstd, g4[j].z, b4[j].z);
-                    o.w = fmaf((v[j].w - mean) * rstd, g4[j].w, b4[j].w);
-                    xw4[i] = o;
-                }
-            }
         } else if (prologue == PRO_LAYERNORM) {
             float t1 = 0.0f, t2 = 0.0f;
             for (int k = lane; k < K; k += 64) {
