@@ -180,7 +180,7 @@ int enqueue_lm_head(zg_gpt* g, hipStream_t s) {
     a.logits_stride = (int)V;
     a.part_val = g->part_val;
     a.part_idx = g->part_idx;
-    const int grid = gemv_plan(a);
+    const int grid = gemv_plan(a, g->wt);
     ZG_REQUIRE(grid == g->lm_grid, ZG_ERR_ARG, "lm_head grid changed");
     return launch_gemv(a, g->wt, grid, s);
 }
@@ -224,7 +224,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.q = g->q;
             a.k_cache = y.k_cache;
             a.v_cache = y.v_cache;
-            const int grid = gemv_plan(a);
+            const int grid = gemv_plan(a, g->wt);
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 1, s));
         }
@@ -256,7 +256,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y_stride = (int)E;
             a.resid = g->x;
             a.resid_stride = (int)E;
-            const int grid = gemv_plan(a);
+            const int grid = gemv_plan(a, g->wt);
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 3, s));
         }
@@ -270,7 +270,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.epilogue = EPI_GELU;
             a.y = g->h4;
             a.y_stride = (int)(4 * E);
-            const int grid = gemv_plan(a);
+            const int grid = gemv_plan(a, g->wt);
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 4, s));
         }
@@ -284,7 +284,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y_stride = (int)E;
             a.resid = g->x;
             a.resid_stride = (int)E;
-            const int grid = gemv_plan(a);
+            const int grid = gemv_plan(a, g->wt);
             ZG_TRY(launch_gemv(a, g->wt, grid, s));
             ZG_TRY(prof_mark(prof, 5, s));
         }
@@ -391,7 +391,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     (void)hipMemset(g->arena + g->weight_region_bytes, 0, g->arena_bytes - g->weight_region_bytes);
     {
         GemvArgs a = base_gemv(g, g->wte, nullptr, c.vocab_size, c.n_embed, 0);
-        g->lm_grid = gemv_plan(a);
+        g->lm_grid = gemv_plan(a, g->wt);
     }
     if (g->lm_grid > 4096) {
         (void)hipFree(g->arena);

@@ -631,6 +631,305 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const GemvArgs a) {
     }
 }
 
+
+// ================================================================================================
+// Batched decode (2 <= M <= 8 sequences in lock step) on the matrix cores.
+//
+// The VALU kernel above re-reads the M input rows from LDS for every weight chunk and ends up bound
+// by LDS traffic and VGPRs (M = 8: 10-17 us per layer GEMV, 38 us for lm_head).  Here one
+// v_mfma_f32_16x16x32_bf16 multiplies 16 weight rows by the (padded) batch for 32 k at once:
+//   B operand = 8 consecutive k of weight row n0 + (lane & 15)  -> one 16-B global load per lane,
+//               straight from the bf16 [N, K] matrix (ops.Linear.weight layout), no staging;
+//   A operand = the input rows, kept in LDS as THREE bf16 planes hi + mid + lo with
+//               hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 mantissa bits carry
+//               the full fp32 value, bf16 x bf16 products are exact in fp32 and the MFMA accumulates
+//               in fp32, so the result has fp32-FMA quality (the north_star 1e-3 bound would not
+//               survive a plain bf16 rounding of the activations: 2^-9 per element);
+//   D          = 16 (batch, 8 used) x 16 (weight rows); lane l holds n = l & 15, m = 4 (l >> 4) + r.
+// A workgroup owns a range of 16-row tiles; its 4 waves split K (each takes every 4th 32-k step) and
+// combine their partial tiles through LDS; wave 0 runs the fused epilogue.
+// ================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float mf_f32x4;
+
+constexpr int kMfmaRows = 8;  // batch rows held in LDS (rows 8..15 of the MFMA tile alias rows 0..7)
+
+__device__ __forceinline__ void split3(float x, bf16_t& hi, bf16_t& mid, bf16_t& lo) {
+    hi = f32_to_bf16_rne(x);
+    const float r1 = x - __uint_as_float((uint32_t)hi << 16);
+    mid = f32_to_bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float((uint32_t)mid << 16);
+    lo = f32_to_bf16_rne(r2);
+}
+
+// planes: [3][kMfmaRows][S] bytes, S = 2 K + 16 (the 16-B pad spreads the rows over the LDS banks)
+__device__ __forceinline__ void store_split4(char* planes, int S, int m, int k, f32x4 v) {
+    bf16_t h[4], md[4], l[4];
+    split3(v.x, h[0], md[0], l[0]);
+    split3(v.y, h[1], md[1], l[1]);
+    split3(v.z, h[2], md[2], l[2]);
+    split3(v.w, h[3], md[3], l[3]);
+    const size_t off = (size_t)m * S + (size_t)k * 2;
+    const size_t plane = (size_t)kMfmaRows * S;
+    *reinterpret_cast<u32x2*>(planes + off) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+    *reinterpret_cast<u32x2*>(planes + plane + off) = u32x2{(uint32_t)md[0] | ((uint32_t)md[1] << 16), (uint32_t)md[2] | ((uint32_t)md[3] << 16)};
+    *reinterpret_cast<u32x2*>(planes + 2 * plane + off) = u32x2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+}
+
+template <int KS, bool ARGMAX, bool SPLITK>  // KS = 32-k steps per wave: K/32 (whole K) or K/32/4 (split K)
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin,
+                                                        int N, int K, int M, int tiles_per_wg, int prologue,
+                                                        int epilogue, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_mf[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = K >> 2, nsteps = K >> 5;
+    const int S = 2 * K + 16;
+    char* planes = smem_mf;                                             // [3][8][S]
+    float* red = reinterpret_cast<float*>(smem_mf + (size_t)3 * kMfmaRows * S);  // LN stats, then partial tiles
+    const int ntiles = (N + 15) >> 4;
+    const int tile_begin = blockIdx.x * tiles_per_wg;
+    const int tile_end = min(tile_begin + tiles_per_wg, ntiles);
+    const int brow = lane & 15, bq = lane >> 4;  // B fragment: weight row within the tile, k quarter
+
+    // ---- 0. first tile's weight fragments: independent of everything else
+    u32x4 wq[KS];
+    auto load_tile = [&](int tile) {
+        const bf16_t* wp = W + (size_t)min(tile * 16 + brow, N - 1) * K + bq * 8;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int st = min(SPLITK ? wave + 4 * i : i, nsteps - 1);  // surplus steps re-read the last one (weight 0 below)
+            wq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + st * 32));
+        }
+    };
+    // SPLITK: the 4 waves share each tile and split K.  Otherwise (very wide matrices: lm_head) every wave
+    // owns whole tiles t, t+4, ...: no per-tile barrier, four epilogues in parallel.
+    const int tile_first = SPLITK ? tile_begin : tile_begin + wave, tile_step = SPLITK ? 1 : 4;
+    load_tile(min(tile_first, ntiles - 1));
+    const int T = a.ctrl ? a.ctrl->seq_len : 1;
+
+    // ---- 1. prologue: transformed input rows -> three bf16 planes in LDS (once per workgroup)
+    if (prologue == PRO_LAYERNORM) {
+        float* stat = red;  // [4 waves][8 rows][2]
+        f32x4 v[kMfmaRows][2], g4[2], b4[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ic = min(tid + 256 * j, nq - 1);
+            g4[j] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+            b4[j] = reinterpret_cast<const f32x4*>(ln_b)[ic];
+#pragma unroll
+            for (int m = 0; m < kMfmaRows; ++m)
+                v[m][j] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[ic];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < kMfmaRows; ++m)
+                if (tid + 256 * j >= nq || m >= M) v[m][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int m = 0; m < kMfmaRows; ++m) {
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                t1 += (v[m][j].x + v[m][j].y) + (v[m][j].z + v[m][j].w);
+                t2 = fmaf(v[m][j].x, v[m][j].x, fmaf(v[m][j].y, v[m][j].y, fmaf(v[m][j].z, v[m][j].z, fmaf(v[m][j].w, v[m][j].w, t2))));
+            }
+            t1 = wave_allsum(t1);
+            t2 = wave_allsum(t2);
+            if (lane == 0) {
+                stat[(wave * kMfmaRows + m) * 2] = t1;
+                stat[(wave * kMfmaRows + m) * 2 + 1] = t2;
+            }
+        }
+        __syncthreads();
+        const float inv_k = 1.0f / (float)K;
+#pragma unroll
+        for (int m = 0; m < kMfmaRows; ++m) {
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s1 += stat[(w * kMfmaRows + m) * 2];
+                s2 += stat[(w * kMfmaRows + m) * 2 + 1];
+            }
+            const float mean = s1 * inv_k;
+            const float rstd = __builtin_amdgcn_rsqf(s2 * inv_k - mean * mean + a.eps);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;
+                if (i < nq) {
+                    f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (m < M) {
+                        o.x = fmaf((v[m][j].x - mean) * rstd, g4[j].x, b4[j].x);
+                        o.y = fmaf((v[m][j].y - mean) * rstd, g4[j].y, b4[j].y);
+                        o.z = fmaf((v[m][j].z - mean) * rstd, g4[j].z, b4[j].z);
+                        o.w = fmaf((v[m][j].w - mean) * rstd, g4[j].w, b4[j].w);
+                    }
+                    store_split4(planes, S, m, i * 4, o);
+                }
+            }
+        }
+    } else if (prologue == PRO_ATTN_MERGE) {
+        const int t_hi = a.t_hi > 0 ? a.t_hi : T;
+        const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
+        for (int i = tid; i < nq; i += 256) {
+            f32x4 o[kMfmaRows];
+#pragma unroll
+            for (int m = 0; m < kMfmaRows; ++m) o[m] = merge_attn4(a, min(m, M - 1), i * 4, nsplit);
+#pragma unroll
+            for (int m = 0; m < kMfmaRows; ++m)
+                store_split4(planes, S, m, i * 4, (m < M) ? o[m] : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+        }
+    } else {
+        for (int i = tid; i < nq; i += 256) {
+            f32x4 o[kMfmaRows];
+#pragma unroll
+            for (int m = 0; m < kMfmaRows; ++m) o[m] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[i];
+#pragma unroll
+            for (int m = 0; m < kMfmaRows; ++m)
+                store_split4(planes, S, m, i * 4, (m < M) ? o[m] : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. tiles
+    Best best[ARGMAX ? 4 : 1];
+#pragma unroll
+    for (int r = 0; r < (ARGMAX ? 4 : 1); ++r) {
+        best[r].val = -3.0e38f;
+        best[r].idx = 0x7fffffff;
+    }
+    const int pos = T - 1;
+    const size_t plane = (size_t)kMfmaRows * S;
+    const char* arow = planes + (size_t)(lane & 7) * S + bq * 16;  // A fragment: batch row (lane & 15) & 7
+    float* part = red + 4 * kMfmaRows * 2;                         // [2 buffers][4 waves][64 lanes][4]
+    int buf = 0;
+    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
+        mf_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int st = SPLITK ? wave + 4 * i : i;
+            const int stc = min(st, nsteps - 1);
+            u32x4 wv = wq[i];
+            if (st >= nsteps) wv = u32x4{0u, 0u, 0u, 0u};
+            const mf_bf16x8 b = __builtin_bit_cast(mf_bf16x8, wv);
+            const mf_bf16x8 a_lo = *reinterpret_cast<const mf_bf16x8*>(arow + 2 * plane + stc * 64);
+            const mf_bf16x8 a_mid = *reinterpret_cast<const mf_bf16x8*>(arow + plane + stc * 64);
+            const mf_bf16x8 a_hi = *reinterpret_cast<const mf_bf16x8*>(arow + stc * 64);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
+        }
+        if (tile + tile_step < tile_end) load_tile(tile + tile_step);  // next tile's weights fly under the epilogue
+        if (SPLITK) {
+            float* mine = part + ((buf * 4 + wave) * 64 + lane) * 4;
+            *reinterpret_cast<mf_f32x4*>(mine) = acc;
+            __syncthreads();
+        }
+        if ((!SPLITK || wave == 0) && lane < 32) {  // lanes 0..31 hold batch rows 0..7
+            mf_f32x4 sum = acc;
+            if (SPLITK) {
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const mf_f32x4 o = *reinterpret_cast<const mf_f32x4*>(part + ((buf * 4 + w) * 64 + lane) * 4);
+                    sum += o;
+                }
+            }
+            const int n = tile * 16 + brow;
+            if (n < N) {
+                const float bias_n = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = bq * 4 + r;
+                    if (m < M) {
+                        const float res = (epilogue == EPI_RESIDUAL) ? a.resid[(size_t)m * a.resid_stride + n] : 0.0f;
+                        epilogue_row(a, m, n, sum[r], bias_n, res, pos, best[ARGMAX ? r : 0]);
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+    }
+
+    // ---- 3. argmax partials: rows m = 4 bq + r live in the 16 lanes of DPP row bq (of wave 0 when K is
+    // split; of every wave otherwise, combined through LDS)
+    if constexpr (ARGMAX) {
+        float* s_val = part;                                   // [4 waves][8 rows]
+        int* s_idx = reinterpret_cast<int*>(part + 32);
+        if (!SPLITK) __syncthreads();                          // tiles done: `part` is free
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Best b = best[r];
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                Best o;
+                o.val = __shfl_xor(b.val, off, 64);
+                o.idx = __shfl_xor(b.idx, off, 64);
+                b = better(b, o);
+            }
+            const int m = bq * 4 + r;
+            if (brow == 0 && lane < 32) {
+                if (SPLITK) {
+                    if (wave == 0 && m < M) {
+                        a.part_val[(size_t)m * gridDim.x + blockIdx.x] = b.val;
+                        a.part_idx[(size_t)m * gridDim.x + blockIdx.x] = b.idx;
+                    }
+                } else {
+                    s_val[wave * 8 + m] = b.val;
+                    s_idx[wave * 8 + m] = b.idx;
+                }
+            }
+        }
+        if (!SPLITK) {
+            __syncthreads();
+            if (tid < kMfmaRows && tid < M) {
+                Best b;
+                b.val = s_val[tid];
+                b.idx = s_idx[tid];
+                for (int w = 1; w < 4; ++w) {
+                    Best o;
+                    o.val = s_val[w * 8 + tid];
+                    o.idx = s_idx[w * 8 + tid];
+                    b = better(b, o);
+                }
+                a.part_val[(size_t)tid * gridDim.x + blockIdx.x] = b.val;
+                a.part_idx[(size_t)tid * gridDim.x + blockIdx.x] = b.idx;
+            }
+        }
+    }
+}
+
+inline size_t gemv_mfma_lds(int K) {
+    return (size_t)3 * kMfmaRows * (2 * K + 16) + (4 * kMfmaRows * 2 + 2 * 4 * 64 * 4) * sizeof(float);
+}
+
+template <int KS, bool ARGMAX, bool SPLITK>
+int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
+    const size_t lds = gemv_mfma_lds(a.K);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, ARGMAX, SPLITK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL((gemv_mfma_kernel<KS, ARGMAX, SPLITK>), dim3(grid), dim3(256), lds, s,
+                       reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K, a.M, a.rows_per_wave, a.prologue,
+                       a.epilogue, a.ln_g, a.ln_b, a);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+// Only the split-K form is dispatched: the whole-K form (SPLITK = false: every wave owns whole tiles, no
+// per-tile barrier) measured slower on lm_head at M = 8 (49.6 vs 27.7 us per launch).
+int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
+    const bool am = a.epilogue == EPI_ARGMAX;
+    const int ks = (a.K / 32 + 3) / 4;
+    if (ks <= 3) return am ? launch_mfma_inst<3, true, true>(a, grid, s) : launch_mfma_inst<3, false, true>(a, grid, s);
+    if (ks <= 6) return am ? launch_mfma_inst<6, true, true>(a, grid, s) : launch_mfma_inst<6, false, true>(a, grid, s);
+    if (ks <= 13) return am ? launch_mfma_inst<13, true, true>(a, grid, s) : launch_mfma_inst<13, false, true>(a, grid, s);
+    return am ? launch_mfma_inst<24, true, true>(a, grid, s) : launch_mfma_inst<24, false, true>(a, grid, s);
+}
+
 template <typename WT, int MT, int LPR, int CPL, bool ARGMAX>
 int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
     const size_t lds = ((size_t)(MT == 1 ? 4 : MT) * a.K + 4 * MT * 2 + 64) * sizeof(float);
@@ -701,7 +1000,25 @@ int gemv_lanes_per_row(int K) {
 
 // Rows per wave: enough waves to cover the chip (256 CUs x 4 SIMDs x 2) without dropping below
 // one double pass (2 * 64/LPR rows) per wave.
-int gemv_plan(GemvArgs& a) {
+// The matrix-core path serves the model tier's lock-step batch: bf16 weights, 2..8 rows, K a
+// multiple of 32 whose three input planes fit in LDS, a fused LayerNorm no wider than 2048.
+bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
+    static const int off = getenv("ZGPT2_NO_GEMV_MFMA") ? atoi(getenv("ZGPT2_NO_GEMV_MFMA")) : 0;
+    if (off || weight_type != WT_BF16 || a.M < 2 || a.M > kMfmaRows) return false;
+    if (a.K % 32 != 0 || a.K / 32 < 4 || a.K / 32 > 96) return false;
+    if (a.prologue == PRO_LAYERNORM && a.K > 2048) return false;
+    return gemv_mfma_lds(a.K) <= 160 * 1024;
+}
+
+int gemv_plan(GemvArgs& a, int weight_type) {
+    if (gemv_use_mfma(a, weight_type)) {
+        const int ntiles = (a.N + 15) / 16;
+        static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
+        int tpw = (ntiles + wgs - 1) / wgs;  // at most ~4 workgroups per CU for the widest matrices
+        if (tpw < 1) tpw = 1;
+        a.rows_per_wave = tpw;            // tiles per workgroup on this path
+        return (ntiles + tpw - 1) / tpw;
+    }
     const int rpp2 = 2 * (64 / gemv_lanes_per_row(a.K));
     const int target_waves = 256 * 4 * 2;
     int rpw = (a.N + target_waves - 1) / target_waves;
@@ -717,6 +1034,7 @@ int gemv_plan(GemvArgs& a) {
 }
 
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
+    if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);
     return weight_type == WT_BF16 ? launch_wt<bf16_t>(a, grid, s) : launch_wt<float>(a, grid, s);
 }
 

@@ -60,7 +60,7 @@ struct GemvArgs {
 };
 
 // Fills rows_per_wave and returns the grid size for the given problem.
-int gemv_plan(GemvArgs& a);
+int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ attention
