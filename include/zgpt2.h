@@ -208,7 +208,9 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
  * one step spends per kernel class (classes 1-5 summed over the layers):
  *   [0] token select + embedding   [1] ln_1 + c_attn + KV append   [2] decode attention
  *   [3] head merge + attn c_proj + residual   [4] ln_2 + c_fc + gelu   [5] mlp c_proj + residual
- *   [6] ln_f + lm_head + argmax     [7] sum of all intervals.
+ *   [6] ln_f + lm_head + argmax     [7] sum of all intervals
+ *   [8] (when n_out >= 9) the interval of a one-element copy kernel recorded the same way: the launch
+ *       boundary + event overhead contained in every interval above.
  * Intervals are event-to-event, so each includes the boundary to the next kernel. */
 int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, size_t n_out);
 

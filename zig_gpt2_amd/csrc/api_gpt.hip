@@ -604,17 +604,27 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
     // All iterations are enqueued before the single synchronisation so that the queue stays ahead of
     // the GPU (an interval then is kernel + launch boundary, not kernel + host launch latency).
     prof.n = 0;
-    for (int it = 0; it < iters; ++it)
+    double null_us = 0.0;
+    for (int it = 0; it < iters; ++it) {
         ZG_TRY(enqueue_step(g, true, bucket_t_hi(g, seq_len + it), s, &prof));  // eager; the embed kernel advances the position
+        // calibration: a one-element copy recorded the same way = launch boundary + event overhead
+        ZG_TRY(launch_copy_f32(g->q, g->q + 4, 1, s));
+        ZG_TRY(prof_mark(&prof, 8, s));
+    }
     ZG_HIP(hipStreamSynchronize(s));
     for (size_t i = 1; i < prof.n; ++i) {
         if (prof.cls[i] < 0) continue;  // interval between two steps
         float ms = 0.0f;
         ZG_HIP(hipEventElapsedTime(&ms, prof.ev[i - 1], prof.ev[i]));
+        if (prof.cls[i] == 8) {
+            null_us += ms * 1000.0;
+            continue;
+        }
         acc[prof.cls[i]] += ms * 1000.0;
         acc[7] += ms * 1000.0;
     }
     for (int i = 0; i < 8; ++i) us_out[i] = (float)(acc[i] / iters);
+    if (n_out >= 9) us_out[8] = (float)(null_us / iters);
     return ZG_OK;
 }
 

@@ -114,9 +114,9 @@ class GPT:
 
     def profile_step(self, seq_len, iters):
         """Average microseconds per kernel class of one eager decode step (zg_gpt_profile_step)."""
-        out = np.zeros(8, np.float32)
+        out = np.zeros(9, np.float32)
         check(self._L.zg_gpt_profile_step(self.h, seq_len, iters, out.ctypes.data_as(_lib.f32p), out.size))
-        return dict(zip(self.PROFILE_CLASSES, (float(v) for v in out)))
+        return dict(zip(self.PROFILE_CLASSES + ["null_kernel_interval"], (float(v) for v in out)))
 
     def time_kernel(self, which, iters):
         us, nbytes = C.c_float(), C.c_size_t()
