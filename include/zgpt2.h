@@ -176,6 +176,15 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
 /* argmax of the logits of the last zg_gpt_forward(compute_logits=1) per sequence (lowest index
  * wins ties) — the greedy replacement for GPT.sample (src/main.zig:198-207). */
 int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens);
+/* GPT.sample — src/main.zig:198-207 for all sequences: zg_gpt_forward(seq_len, tokens, logits), then
+ * logits /= temp, softmax, and an index drawn with probability proportional to the result
+ * (std.rand weightedIndex: first index whose running sum exceeds u * total).  The reference re-seeds
+ * its PRNG from the wall clock on every call; here the uniforms u[b] in [0,1) are supplied by the
+ * caller (uniforms == NULL: derived from `seed`, seq_len and b with the library's counter PRNG), so a
+ * run is reproducible.  probs_out (host or device, [batch, vocab]) optionally receives the softmax. */
+int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens, float temp,
+                  const float* uniforms, uint64_t seed, size_t* tokens_out, float* probs_out, size_t probs_len);
+
 /* ln_f output of the last forward, [batch, n_embed] (state.x, main.zig:189). */
 int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len);
 

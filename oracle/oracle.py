@@ -84,6 +84,8 @@ def _declare(L):
     L.orc_gpt_forward.argtypes = [C.c_void_p, sz, sz, i]
     L.orc_gpt_sample_greedy.argtypes = [C.c_void_p, sz, sz]
     L.orc_gpt_sample_greedy.restype = sz
+    L.orc_gpt_sample.argtypes = [C.c_void_p, sz, sz, f, f]
+    L.orc_gpt_sample.restype = sz
     L.orc_gpt_generate_greedy.argtypes = [C.c_void_p, szp, sz, sz, szp, f32p]
     L.orc_gpt_forced_logits.argtypes = [C.c_void_p, szp, sz, sz, f32p]
 
@@ -259,6 +261,11 @@ class GPT:
         if compute_logits:
             return np.ctypeslib.as_array(lib().orc_gpt_logits(self.h), (self.cfg.vocab_size,)).copy()
         return None
+
+    def sample(self, seq_len, token, temp, u):
+        """GPT.sample (src/main.zig:198-207) with the uniform draw u supplied; returns (token, probs)."""
+        t = lib().orc_gpt_sample(self.h, seq_len, token, temp, u)
+        return int(t), np.ctypeslib.as_array(lib().orc_gpt_logits(self.h), (self.cfg.vocab_size,)).copy()
 
     def hidden(self):
         return np.ctypeslib.as_array(lib().orc_gpt_x(self.h), (self.cfg.n_embed,)).copy()

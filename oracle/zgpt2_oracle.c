@@ -532,6 +532,27 @@ size_t orc_gpt_sample_greedy(orc_gpt* g, size_t seq_len, size_t token) {
     return best;
 }
 
+/* GPT.sample — main.zig:198-207: forward with logits; logits /= temp (:200-202); softmax (:203);
+ * random.weightedIndex(f32, logits) (:204-206).  The reference seeds a fresh PRNG from the wall clock on
+ * every call, so its draw is not reproducible; here the uniform u in [0,1) is an argument.  weightedIndex
+ * (Zig std.rand) picks `point = u * sum(weights)` and returns the first index whose running sum exceeds
+ * it (the last index if rounding leaves none). */
+size_t orc_gpt_sample(orc_gpt* g, size_t seq_len, size_t token, float temp, float u) {
+    orc_gpt_forward(g, seq_len, token, 1);
+    const size_t V = g->config.vocab_size;
+    for (size_t i = 0; i < V; ++i) g->logits[i] /= temp;
+    orc_softmax(g->logits, V);
+    float sum = 0.0f;
+    for (size_t i = 0; i < V; ++i) sum += g->logits[i];
+    const float point = u * sum;
+    float acc = 0.0f;
+    for (size_t i = 0; i < V; ++i) {
+        acc += g->logits[i];
+        if (point < acc) return i;
+    }
+    return V - 1;
+}
+
 /* generate — main.zig:322-342, greedy.  Runs n_steps (<= context_size; the reference always runs
  * context_size, :330) iterations; prompt tokens are fed one at a time without logits (:331-334),
  * then sample(s+1, token) re-feeds the previous token at the next position (:337) — so the last

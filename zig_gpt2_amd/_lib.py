@@ -61,6 +61,7 @@ SIGNATURES = {
     "zg_gpt_step_bytes": (C.c_int, [vp, sz, szp, szp]),
     "zg_gpt_forward": (C.c_int, [vp, sz, vp, sz, C.c_int, vp, sz]),
     "zg_gpt_argmax": (C.c_int, [vp, vp, sz]),
+    "zg_gpt_sample": (C.c_int, [vp, sz, vp, sz, C.c_float, vp, C.c_uint64, vp, vp, sz]),
     "zg_gpt_hidden": (C.c_int, [vp, vp, sz]),
     "zg_gpt_generate_greedy": (C.c_int, [vp, vp, sz, vp, sz, vp, sz]),
     "zg_gpt_generate_enqueue": (C.c_int, [vp, vp, sz, vp, sz]),

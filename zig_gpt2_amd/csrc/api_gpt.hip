@@ -521,6 +521,39 @@ int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens) {
     return ZG_OK;
 }
 
+int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens, float temp, const float* uniforms,
+                  uint64_t seed, size_t* tokens_out, float* probs_out, size_t probs_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && tokens && tokens_out && temp > 0.0f, ZG_ERR_ARG, "gpt_sample: bad argument");
+    const size_t V = g->cfg.vocab_size, B = g->batch;
+    ZG_REQUIRE(!probs_out || probs_len >= B * V, ZG_ERR_SHAPE, "gpt_sample: probs_out needs %zu elements", B * V);
+    ZG_TRY(zg_gpt_forward(g, seq_len, tokens, n_tokens, 1, nullptr, 0));  // main.zig:199
+    hipStream_t s = ctx().stream;
+    float* h_u = reinterpret_cast<float*>(g->h_ints);
+    for (size_t b = 0; b < B; ++b) {
+        if (uniforms) {
+            ZG_REQUIRE(uniforms[b] >= 0.0f && uniforms[b] < 1.0f, ZG_ERR_ARG, "gpt_sample: uniform %f outside [0,1)", uniforms[b]);
+            h_u[b] = uniforms[b];
+        } else {  // counter PRNG (splitmix64 finaliser, 24 random bits), same construction as the synthetic weights
+            uint64_t z = seed * 0x9E3779B97F4A7C15ULL + (uint64_t)seq_len * 0xD1B54A32D192ED03ULL + b + 1;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            h_u[b] = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+        }
+    }
+    float* d_u = g->q;  // scratch: q is dead after the forward
+    ZG_HIP(hipMemcpyAsync(d_u, h_u, B * sizeof(float), hipMemcpyHostToDevice, s));
+    ZG_TRY(launch_sample(g->logits, (int)B, (int)V, temp, d_u, g->cur_token, s));  // main.zig:200-206
+    ZG_HIP(hipMemcpyAsync(g->h_ints + B, g->cur_token, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (probs_out)
+        ZG_HIP(hipMemcpyAsync(probs_out, g->logits, B * V * sizeof(float),
+                              is_device_ptr(probs_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; ++b) tokens_out[b] = (size_t)g->h_ints[B + b];
+    return ZG_OK;
+}
+
 int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && x_out && len >= g->batch * g->cfg.n_embed, ZG_ERR_ARG, "gpt_hidden: bad argument");

@@ -202,6 +202,58 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const EmbedArgs a) {
     }
 }
 
+// Sampler tail of GPT.sample (src/main.zig:200-206): one workgroup per sequence, in place on its logits
+// row: p = softmax(logits / temp); token = first index whose running sum of p exceeds u * sum(p).
+__global__ __launch_bounds__(1024) void sample_kernel(float* logits, int vocab, float inv_temp, const float* u,
+                                                      int* token_out) {
+    __shared__ float s_red[16];
+    __shared__ float s_scan[1024];
+    float* x = logits + (size_t)blockIdx.x * vocab;
+    const int tid = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int i = tid; i < vocab; i += 1024) mx = fmaxf(mx, x[i] * inv_temp);
+    mx = block_allmax(mx, s_red);
+    // each thread owns a contiguous chunk so that the running sum follows index order
+    const int chunk = (vocab + 1023) / 1024, lo = tid * chunk, hi = min(lo + chunk, vocab);
+    float local = 0.0f;
+    for (int i = lo; i < hi; ++i) {
+        const float e = __expf(x[i] * inv_temp - mx);
+        x[i] = e;
+        local += e;
+    }
+    const float total = block_allsum(local, s_red);
+    const float inv = 1.0f / total;
+    for (int i = lo; i < hi; ++i) x[i] *= inv;  // probabilities, like the reference leaves in state.logits
+    local *= inv;
+    s_scan[tid] = local;
+    __syncthreads();
+    if (tid == 0) {  // 1024 partial sums: a serial scan keeps the reference's left-to-right order
+        float acc = 0.0f;
+        for (int t = 0; t < 1024; ++t) {
+            const float v = s_scan[t];
+            s_scan[t] = acc;  // exclusive prefix
+            acc += v;
+        }
+        s_red[0] = acc;
+    }
+    __syncthreads();
+    const float point = u[blockIdx.x] * s_red[0];
+    const float before = s_scan[tid];
+    const bool last = lo < hi && hi == vocab;  // the thread owning the final chunk also catches point >= total
+    if (lo < hi && point >= before && (point < before + local || last)) {
+        float acc = before;
+        int pick = hi - 1;
+        for (int i = lo; i < hi; ++i) {
+            acc += x[i];
+            if (point < acc) {
+                pick = i;
+                break;
+            }
+        }
+        atomicMin(&token_out[blockIdx.x], pick);
+    }
+}
+
 inline int grid_for(size_t n, int block = 256, int cap = 2048) {
     size_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -271,6 +323,13 @@ int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s) {
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
     if (n == 0) return ZG_OK;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s) {
+    ZG_HIP(hipMemsetAsync(token_out, 0x7f, batch * sizeof(int), s));  // atomicMin target
+    hipLaunchKernelGGL(sample_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, 1.0f / temp, u, token_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -98,6 +98,9 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
                         bool gelu, bool out_bf16, hipStream_t s);
 
+// GPT.sample tail: in-place softmax(logits / temp) per sequence + inverse-CDF draw with uniform u[b].
+int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s);
+
 // Decode-step head kernel: token selection (+ argmax finalisation of the previous step) and
 // x = wte[token] + wpe[pos].
 struct EmbedArgs {

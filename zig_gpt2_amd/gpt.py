@@ -71,6 +71,16 @@ class GPT:
                                      ops._n(logits)))
         return logits
 
+    def sample(self, seq_len, tokens, temp, uniforms=None, seed=0, want_probs=False):
+        """GPT.sample (src/main.zig:198-207) with reproducible uniforms; returns tokens [batch] (and probs)."""
+        tokens = np.ascontiguousarray(np.atleast_1d(tokens), dtype=np.uint64)
+        u = None if uniforms is None else np.ascontiguousarray(np.atleast_1d(uniforms), dtype=np.float32)
+        out = np.zeros(self.batch, np.uint64)
+        probs = np.empty((self.batch, self.config.vocab_size), np.float32) if want_probs else None
+        check(self._L.zg_gpt_sample(self.h, seq_len, ptr(tokens), tokens.size, temp, ptr(u), seed, ptr(out), ptr(probs),
+                                    ops._n(probs)))
+        return (out, probs) if want_probs else out
+
     def argmax(self):
         out = np.zeros(self.batch, np.uint64)
         check(self._L.zg_gpt_argmax(self.h, ptr(out), out.size))
