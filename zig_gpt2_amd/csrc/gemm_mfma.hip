@@ -298,7 +298,8 @@ int launch_gemm_deep_t(const bf16_t* A, const bf16_t* B, const float* bias, void
 // c ^ ((r >> 2) & 3), which makes the 16-lane groups of ds_read_b128 conflict free.
 constexpr int QM = 256, QN = 256, QK = 32;
 constexpr int kQStage = (QM + QN) * QK * 2;  // 32 KiB
-constexpr int kQLds = 4 * kQStage;           // 128 KiB
+constexpr int kQSlots = 5;                   // ring slots: 4 stages in flight + the one being multiplied
+constexpr int kQLds = kQSlots * kQStage;     // 160 KiB: the whole LDS of a CU
 
 __device__ __forceinline__ void stage_q(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int K, int m0,
                                         int n0, int k0, char* slot, int wave, int lane) {
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_q_kernel(const bf16_t* __
         }
     }
     const int m0 = tm * QM, n0 = tn * QN;
+    // diagnostic (ZGPT2_ABLATE=8): stage every tile from the same panels (all-L2-hit upper bound)
+    const int ms = (ablate & 8) ? 0 : m0, ns = (ablate & 8) ? 0 : n0;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -361,9 +364,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_q_kernel(const bf16_t* __
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nt = K / QK;
-    stage_q(A, B, K, m0, n0, 0, lds, wave, lane);
-    if (nt > 1) stage_q(A, B, K, m0, n0, QK, lds + kQStage, wave, lane);
-    if (nt > 2) stage_q(A, B, K, m0, n0, 2 * QK, lds + 2 * kQStage, wave, lane);
+#pragma unroll
+    for (int st = 0; st < kQSlots - 1; ++st)
+        if (st < nt) stage_q(A, B, K, ms, ns, st * QK, lds + st * kQStage, wave, lane);
 
     const int frow = lane & 31, fk = lane >> 5;
     // Role-split schedule.  The two waves that share a SIMD (w and w + 4) run half a stage out of phase:
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_q_kernel(const bf16_t* __
     const int grp = wave >> 2;
     bf16x8 fa[2][4], fb[2][2];
     auto load_stage = [&](int stage) {
-        const char* cur = lds + (stage & 3) * kQStage;
+        const char* cur = lds + (stage % kQSlots) * kQStage;
         const char* curB = cur + QM * QK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -402,13 +405,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_q_kernel(const bf16_t* __
     // even barrier of stage s: wait for the stage, synchronise, refill the slot freed one stage ago
     auto even_barrier = [&](int st) {
         if (st < nt) {
-            const int ahead = nt - 1 - st;  // stages issued beyond st (at most 2)
-            if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0f78);       // vmcnt(8)
+            const int ahead = min(nt - 1 - st, kQSlots - 2);  // stages issued beyond st (4 loads each)
+            if (ahead >= 3) __builtin_amdgcn_s_waitcnt(0x0f7c);       // vmcnt(12)
+            else if (ahead == 2) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
             else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4)
             else __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
         }
         __builtin_amdgcn_s_barrier();
-        if (st + 3 < nt) stage_q(A, B, K, m0, n0, (st + 3) * QK, lds + ((st + 3) & 3) * kQStage, wave, lane);
+        const int nx = st + kQSlots - 1;  // its slot was last read one stage ago (group 1, interval 2 st - 1)
+        if (nx < nt) stage_q(A, B, K, ms, ns, nx * QK, lds + (nx % kQSlots) * kQStage, wave, lane);
     };
     // Both groups execute exactly 2 * nt + 1 barriers.
     if (grp == 0) {
@@ -485,6 +490,193 @@ int launch_gemm_q_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C
     return ZG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, FULL-LINE staging.  The BK = 32 ring above asks L2 for every 128-B line twice (64 B per
+// row per stage) and tops out at ~14 B/clk/CU of LDS-DMA; the BK = 64 kernels move ~19 B/clk/CU.  Here a
+// ring unit is HALF the rows (128 of A + 128 of B) for 64 k: 32 pieces of 8 rows x 128 B, so each line is
+// requested once.  K-step T (64 k) consumes units 2T (row half 0) and 2T + 1 (row half 1); 5 slots of
+// 32 KiB; after barrier T the units 2T+3 and 2T+4 are issued into the slots step T-1 just released.
+template <bool GELU, bool OUT_BF16, int MF>  // MF = 32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __restrict__ A,
+                                                                const bf16_t* __restrict__ B,
+                                                                const float* __restrict__ bias, void* __restrict__ C,
+                                                                int M, int N, int K, int ldc, int tiles_n, int n_tiles,
+                                                                int gw) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int bid = blockIdx.x;
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    int tm, tn;
+    {
+        const int tiles_m = n_tiles / tiles_n;
+        const int band = tile / (tiles_m * gw), full = tiles_n / gw;
+        if (band < full) {
+            const int r = tile - band * tiles_m * gw;
+            tm = r / gw;
+            tn = band * gw + r % gw;
+        } else {
+            const int w = tiles_n - full * gw, r = tile - full * tiles_m * gw;
+            tm = r / w;
+            tn = full * gw + r % w;
+        }
+    }
+    const int m0 = tm * QM, n0 = tn * QN;
+
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    f32x16 acc[4][2];     // MF == 32: 4 x 2 tiles of 32 x 32
+    f32x4v acc16[8][4];   // MF == 16: 8 x 4 tiles of 16 x 16
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int nt = K / 64, nu = 2 * nt;
+    // unit u -> K-step u >> 1, row half u & 1; each wave issues 4 pieces (2 of A, 2 of B)
+    auto issue_unit = [&](int u) {
+        char* slot = lds + (u % 5) * 32768;
+        const int k0 = (u >> 1) * 64, half = u & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = wave * 4 + q;                 // 0..31: 16 A pieces then 16 B pieces, 8 rows each
+            const bool isB = piece >= 16;
+            const int prow = (isB ? piece - 16 : piece) * 8 + (lane >> 3);  // row inside the 128-row half
+            const int pos = lane & 7;
+            const int chunk = pos ^ ((prow >> 1) & 7);
+            const bf16_t* src = (isB ? B + (size_t)(n0 + half * 128 + prow) * K : A + (size_t)(m0 + half * 128 + prow) * K) +
+                                k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(slot + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue_unit(0);
+    if (nu > 1) issue_unit(1);
+    if (nu > 2) issue_unit(2);
+
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int T = 0; T < nt; ++T) {
+        if (T + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4): units 2T, 2T+1 landed; 2T+2 may fly
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        if (2 * T + 3 < nu) issue_unit(2 * T + 3);
+        if (2 * T + 4 < nu) issue_unit(2 * T + 4);
+        const char* ua = lds + ((2 * T + wm) % 5) * 32768;                 // A half wm
+        const char* ub = lds + ((2 * T + (wn >> 1)) % 5) * 32768 + 16384;  // B half wn >> 1
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (MF == 16) {
+            const int r16 = lane & 15, q16 = lane >> 4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {  // two 32-k substeps per unit pair
+                bf16x8 a[8], b[4];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = read_frag(ua, i * 16 + r16, kk * 4 + q16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = read_frag(ub, (wn & 1) * 64 + j * 16 + r16, kk * 4 + q16);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc16[i][j], 0, 0, 0);
+            }
+        } else
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = read_frag(ua, i * 32 + frow, kk * 2 + fk);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = read_frag(ub, (wn & 1) * 64 + j * 32 + frow, kk * 2 + fk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
+
+    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    constexpr int ROW_BYTES = 64 * ESZ, CHUNKS_PER_ROW = ROW_BYTES / 16, CHUNKS = 64 * CHUNKS_PER_ROW;
+    char* wtile = lds + wave * (64 * 64 * 4);
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[j] = bias ? bias[n0 + wn * 64 + j * 32 + frow] : 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + frow;
+            if constexpr (MF == 32) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                        float v = acc[half * 2 + ii][j][r] + bv[j];
+                        if (GELU) v = gelu_fast(v);
+                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = f32_to_bf16_rne(v);
+                        else reinterpret_cast<float*>(wtile)[row * 64 + col] = v;
+                    }
+            }
+        }
+        if constexpr (MF == 16) {  // D: col = lane & 15, row = 4 (lane >> 4) + r
+            const int c16 = lane & 15, q16 = lane >> 4;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float b16 = bias ? bias[n0 + wn * 64 + jj * 16 + c16] : 0.0f;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = ii * 16 + q16 * 4 + r;
+                        float v = acc16[half * 4 + ii][jj][r] + b16;
+                        if (GELU) v = gelu_fast(v);
+                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + jj * 16 + c16] = f32_to_bf16_rne(v);
+                        else reinterpret_cast<float*>(wtile)[row * 64 + jj * 16 + c16] = v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < CHUNKS / 64; ++it) {
+            const int c = it * 64 + lane;
+            const int row = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + row * ROW_BYTES + cc * 16);
+            char* dst = reinterpret_cast<char*>(C) +
+                        ((size_t)(m0 + wm * 128 + half * 64 + row) * ldc + n0 + wn * 64) * ESZ + cc * 16;
+            *reinterpret_cast<u32x4*>(dst) = v;
+        }
+    }
+}
+
+template <bool GELU, bool OUT_BF16, int MF>
+int launch_gemm_f_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                    hipStream_t s) {
+    static bool raised = false;
+    if (!raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_f_kernel<GELU, OUT_BF16, MF>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+        raised = true;
+    }
+    const int tiles_m = M / QM, tiles_n = N / QN;
+    static const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
+    int gw = gw_env > 0 ? gw_env : 6;
+    if (gw > tiles_n) gw = tiles_n;
+    hipLaunchKernelGGL((gemm_nt_bf16_f_kernel<GELU, OUT_BF16, MF>), dim3(tiles_m * tiles_n), dim3(512), 5 * 32768, s, A, B,
+                       bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n, gw);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 }  // namespace
 
 int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
@@ -493,7 +685,19 @@ int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, voi
                "gemm_bf16_nt: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, BM, BN, BK);
     ZG_REQUIRE(ldc >= N && ldc % 8 == 0, ZG_ERR_ARG, "gemm_bf16_nt: ldc %d", ldc);
     static const int variant = getenv("ZGPT2_GEMM") ? atoi(getenv("ZGPT2_GEMM")) : 0;  // 1: force 128x128
-    if (M % QM == 0 && N % QN == 0 && (variant == 0 || variant == 3)) {
+    if (M % QM == 0 && N % QN == 0 && K % 64 == 0 && (variant == 0 || variant == 5)) {
+        if (gelu) return out_bf16 ? launch_gemm_f_t<true, true, 16>(A, B, bias, C, M, N, K, ldc, s)
+                                  : launch_gemm_f_t<true, false, 16>(A, B, bias, C, M, N, K, ldc, s);
+        return out_bf16 ? launch_gemm_f_t<false, true, 16>(A, B, bias, C, M, N, K, ldc, s)
+                        : launch_gemm_f_t<false, false, 16>(A, B, bias, C, M, N, K, ldc, s);
+    }
+    if (M % QM == 0 && N % QN == 0 && K % 64 == 0 && variant == 4) {
+        if (gelu) return out_bf16 ? launch_gemm_f_t<true, true, 32>(A, B, bias, C, M, N, K, ldc, s)
+                                  : launch_gemm_f_t<true, false, 32>(A, B, bias, C, M, N, K, ldc, s);
+        return out_bf16 ? launch_gemm_f_t<false, true, 32>(A, B, bias, C, M, N, K, ldc, s)
+                        : launch_gemm_f_t<false, false, 32>(A, B, bias, C, M, N, K, ldc, s);
+    }
+    if (M % QM == 0 && N % QN == 0 && variant == 3) {
         if (gelu) return out_bf16 ? launch_gemm_q_t<true, true>(A, B, bias, C, M, N, K, ldc, s)
                                   : launch_gemm_q_t<true, false>(A, B, bias, C, M, N, K, ldc, s);
         return out_bf16 ? launch_gemm_q_t<false, true>(A, B, bias, C, M, N, K, ldc, s)
