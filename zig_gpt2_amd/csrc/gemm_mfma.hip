@@ -186,9 +186,19 @@ __device__ __forceinline__ void stage_deep(const bf16_t* __restrict__ A, const b
     }
 }
 
+// gelu(x) = x / (1 + exp(-2u)), u = x * 0.7978845608 * (1 + 0.044715 x^2)  (src/ops.zig:225), with the
+// -2 log2(e) factor folded into the polynomial so that the exponential is a bare v_exp_f32.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float u = x * 0.7978845608f * (1.0f + 0.044715f * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
+    const float arg = x * fmaf(x * x, k2, k1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+}
+
+// fp32 -> bf16 (round to nearest even) in one instruction (gfx950 v_cvt_pk_bf16_f32).
+__device__ __forceinline__ bf16_t cvt_bf16(float x) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return (bf16_t)r;
 }
 
 template <bool GELU, bool OUT_BF16>
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ B,
                                                                 const float* __restrict__ bias, void* __restrict__ C,
                                                                 int M, int N, int K, int ldc, int tiles_n, int n_tiles,
-                                                                int gw) {
+                                                                int gw, int ablate) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -604,6 +614,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __
         __builtin_amdgcn_s_setprio(0);
     }
     __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
+    if (ablate & 32) {  // diagnostic: no epilogue at all (keep the accumulators alive)
+        float t = 0.0f;
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) t += acc16[i][j][0];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) t += acc[i][j][0];
+        if (t == 1.2345f) reinterpret_cast<float*>(C)[0] = t;
+        return;
+    }
 
     constexpr int ESZ = OUT_BF16 ? 2 : 4;
     constexpr int ROW_BYTES = 64 * ESZ, CHUNKS_PER_ROW = ROW_BYTES / 16, CHUNKS = 64 * CHUNKS_PER_ROW;
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __
                         const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                         float v = acc[half * 2 + ii][j][r] + bv[j];
                         if (GELU) v = gelu_fast(v);
-                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = f32_to_bf16_rne(v);
+                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = cvt_bf16(v);
                         else reinterpret_cast<float*>(wtile)[row * 64 + col] = v;
                     }
             }
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __
                         const int row = ii * 16 + q16 * 4 + r;
                         float v = acc16[half * 4 + ii][jj][r] + b16;
                         if (GELU) v = gelu_fast(v);
-                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + jj * 16 + c16] = f32_to_bf16_rne(v);
+                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + jj * 16 + c16] = cvt_bf16(v);
                         else reinterpret_cast<float*>(wtile)[row * 64 + jj * 16 + c16] = v;
                     }
             }
@@ -653,7 +670,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __
             const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + row * ROW_BYTES + cc * 16);
             char* dst = reinterpret_cast<char*>(C) +
                         ((size_t)(m0 + wm * 128 + half * 64 + row) * ldc + n0 + wn * 64) * ESZ + cc * 16;
-            *reinterpret_cast<u32x4*>(dst) = v;
+            if (!(ablate & 16)) *reinterpret_cast<u32x4*>(dst) = v;
+            else if (v.x == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = v;
         }
     }
 }
@@ -672,7 +690,8 @@ int launch_gemm_f_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C
     int gw = gw_env > 0 ? gw_env : 6;
     if (gw > tiles_n) gw = tiles_n;
     hipLaunchKernelGGL((gemm_nt_bf16_f_kernel<GELU, OUT_BF16, MF>), dim3(tiles_m * tiles_n), dim3(512), 5 * 32768, s, A, B,
-                       bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n, gw);
+                       bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n, gw,
+                       getenv("ZGPT2_ABLATE") ? atoi(getenv("ZGPT2_ABLATE")) : 0);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
