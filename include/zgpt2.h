@@ -141,7 +141,8 @@ enum {
     ZG_GPT_WEIGHTS_BF16 = 0,     /* Linear/embedding matrices stored bf16 (RNE) — default */
     ZG_GPT_WEIGHTS_F32 = 1 << 0, /* keep matrices in fp32 (exact with arbitrary checkpoints) */
     ZG_GPT_NO_GRAPH = 1 << 1,    /* launch kernels eagerly instead of replaying a hipGraph */
-    ZG_GPT_KV_F16 = 1 << 2       /* store the KV cache as fp16 instead of fp32 */
+    ZG_GPT_KV_F16 = 1 << 2,      /* store the KV cache as fp16 instead of fp32 */
+    ZG_GPT_NO_PREFILL = 1 << 3   /* generate: feed prompts one position at a time, as main.zig:331-334 does */
 };
 
 /* Per-block tensor slots (load_block, src/main.zig:271-302) and top-level slots (load_gpt,
@@ -172,6 +173,14 @@ int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* k
  * position seq_len-1.  If logits_out != NULL (host or device, [batch, vocab]) it receives
  * state.logits and the call is synchronous; compute_logits == 0 skips lm_head (main.zig:192). */
 int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens,
+                   int compute_logits, float* logits_out, size_t logits_len);
+/* The prompt loop of generate (src/main.zig:331-334: gpt.forward(i + 1, prompt[i], ...) for every prompt
+ * position) as ONE pass: positions 0..n_tokens-1 of all `batch` sequences go through each Block together
+ * (Linears as matrix-core GEMMs, causal attention), filling the KV caches exactly as n_tokens calls of
+ * zg_gpt_forward would.  tokens is [batch][token_stride].  With compute_logits != 0 the logits of position
+ * n_tokens-1 are produced as zg_gpt_forward(n_tokens, ...) would (zg_gpt_argmax / logits_out as there).
+ * Afterwards decoding continues with zg_gpt_forward(n_tokens + 1, ...).  bf16-weight handles only. */
+int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t n_tokens,
                    int compute_logits, float* logits_out, size_t logits_len);
 /* argmax of the logits of the last zg_gpt_forward(compute_logits=1) per sequence (lowest index
  * wins ties) — the greedy replacement for GPT.sample (src/main.zig:198-207). */

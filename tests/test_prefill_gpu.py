@@ -1,0 +1,144 @@
+"""Whole-prompt forward (zg_gpt_prefill) on a real MI355X.
+
+The reference feeds a prompt one position at a time through GPT.forward (src/main.zig:331-334); the
+prefill pass must leave the KV caches and the last-position logits in the state those calls would:
+checked against the CPU oracle (which does exactly that loop), against the golden vectors of the
+reference's PyTorch GPT, and against the library's own decode path at the full 124M / 1024-token size.
+Tolerance is the model tolerance of golden_io.assert_model_close (1e-3 relative, north_star).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from golden_io import assert_greedy_ids_match, assert_model_close, load_gpt
+from zig_gpt2_amd import _lib
+from zig_gpt2_amd import gpt as zgpt
+from zig_gpt2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make(cfg, seed, **kw):
+    w = synth.make_weights(cfg, seed=seed, bf16=True)
+    m = zgpt.GPT(cfg, **kw)
+    m.load_weights(w)
+    return m, w
+
+
+@pytest.mark.parametrize("name,lengths", [("tiny", [1, 2, 5, 31, 32, 33, 64]), ("tiny3", [7, 48]),
+                                          ("nano-char", [3, 127, 128, 129, 256])])
+def test_prefill_logits_and_cache_match_oracle(zg, name, lengths):
+    """logits of position n-1 after prefill(n tokens) == oracle after n GPT.forward calls; then one decode
+    step on top of the prefilled caches == the oracle's next step (pins the KV cache contents)."""
+    cfg = synth.CONFIGS[name]
+    m, w = make(cfg, 71)
+    for n in lengths:
+        toks = synth.rand_tokens(700 + n, min(n + 1, cfg.context_size), cfg.vocab_size)
+        ref = oracle.GPT(cfg, w)
+        lg_ref = ref.forced_logits(toks, n - 1)
+        lg = m.prefill([toks[:n]])
+        assert_model_close(lg_ref[0], lg[0], f"{name} prefill n={n}")
+        assert int(m.argmax()[0]) == int(np.argmax(lg[0]))
+        if n < cfg.context_size:
+            nxt = m.forward(n + 1, [toks[n]])
+            assert_model_close(lg_ref[1], nxt[0], f"{name} decode after prefill n={n}")
+    m.close()
+
+
+@pytest.mark.parametrize("kv_f16", [False, True])
+def test_prefill_batched_rows_are_independent(zg, kv_f16):
+    cfg = synth.CONFIGS["tiny"]
+    m, w = make(cfg, 72, batch=3, kv_f16=kv_f16)
+    n = 21
+    toks = np.stack([synth.rand_tokens(720 + b, n + 1, cfg.vocab_size) for b in range(3)])
+    lg = m.prefill(toks[:, :n])
+    nxt = m.forward(n + 1, toks[:, n])
+    for b in range(3):
+        lg_ref = oracle.GPT(cfg, w).forced_logits(toks[b], n - 1)
+        assert_model_close(lg_ref[0], lg[b], f"row {b} prefill")
+        if kv_f16:  # fp16 cache: not the parity default, 1e-3 of the logit scale (test_gpt_gpu.py)
+            rms = float(np.sqrt(np.mean(lg_ref[1].astype(np.float64) ** 2)))
+            assert np.abs(nxt[b] - lg_ref[1]).max() <= 1e-3 * rms
+        else:
+            assert_model_close(lg_ref[1], nxt[b], f"row {b} decode after prefill")
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "nano-char", "124M"])
+def test_generate_with_and_without_prefill_match_reference_gpt(zg, name):
+    cfg, g = load_gpt(name)
+    n_steps, n_prompt = len(g["out_tokens"]), len(g["prompt"])
+    out = {}
+    for prefill in (True, False):
+        m, _ = make(cfg, int(g["weight_seed"]), prefill=prefill)
+        ids = m.generate([g["prompt"]], n_steps)[0]
+        assert np.array_equal(ids[:n_prompt], g["prompt"])
+        assert_greedy_ids_match(g["out_tokens"][n_prompt:], ids[n_prompt:], g["top1"], g["top2"], f"{name} prefill={prefill}")
+        out[prefill] = ids
+        m.close()
+    assert_greedy_ids_match(out[False][n_prompt:], out[True][n_prompt:], g["top1"], g["top2"], f"{name} prefill vs loop")
+
+
+def test_generate_ragged_prompts_prefill_shared_prefix_length(zg):
+    """Batched prompts of different lengths: positions below the shortest prompt are prefilled, the rest
+    go through the decode loop; every row must equal an independent reference-style generation."""
+    cfg = synth.CONFIGS["tiny"]
+    m, w = make(cfg, 73, batch=4)
+    lens = [9, 6, 17, 6]
+    prompts = [synth.rand_tokens(730 + b, lens[b], cfg.vocab_size) for b in range(4)]
+    ids = m.generate(prompts, cfg.context_size)
+    for b in range(4):
+        ids_ref, lg = oracle.GPT(cfg, w).generate_greedy(prompts[b], cfg.context_size, want_logits=True)
+        top = np.sort(lg, axis=1)
+        assert np.array_equal(ids[b, : lens[b]], prompts[b])
+        assert_greedy_ids_match(ids_ref[lens[b]:], ids[b, lens[b]:], top[:, -1], top[:, -2], f"row {b}")
+    # n_steps shorter than the prompts: nothing is generated, the prompt prefix comes back
+    short = m.generate(prompts, 5)
+    for b in range(4):
+        assert np.array_equal(short[b], prompts[b][:5])
+    m.close()
+
+
+def test_prefill_124m_full_context_equals_decode_loop(zg):
+    """BASELINE size: a 1023-token prompt prefilled in one pass vs fed token by token; the logits of the
+    last position and of the following decode step must agree within the model tolerance, and the
+    prefilled generation must continue with the same greedy ids."""
+    cfg = synth.CONFIGS["124M"]
+    w = synth.make_weights(cfg, seed=0, bf16=True)
+    n = cfg.context_size - 1
+    toks = synth.rand_tokens(74, n + 1, cfg.vocab_size)
+    a = zgpt.GPT(cfg)
+    a.load_weights(w)
+    for s in range(n - 1):
+        a.forward(s + 1, [toks[s]], compute_logits=False)
+    lg_loop = a.forward(n, [toks[n - 1]])
+    nxt_loop = a.forward(n + 1, [toks[n]])
+    lg = a.prefill([toks[:n]])
+    nxt = a.forward(n + 1, [toks[n]])
+    assert np.isfinite(lg).all()
+    assert_model_close(lg_loop[0], lg[0], "124M prefill 1023 vs loop")
+    assert_model_close(nxt_loop[0], nxt[0], "124M decode after prefill vs loop")
+    a.close()
+    # oracle spot check at a length it finishes in seconds
+    ref = oracle.GPT(cfg, w)
+    k = 80
+    lg_ref = ref.forced_logits(toks[: k + 1], k - 1)
+    b = zgpt.GPT(cfg)
+    b.load_weights(w)
+    assert_model_close(lg_ref[0], b.prefill([toks[:k]])[0], "124M prefill 80 vs oracle")
+    assert_model_close(lg_ref[1], b.forward(k + 1, [toks[k]])[0], "124M decode after prefill 80 vs oracle")
+    b.close()
+
+
+def test_prefill_errors(zg):
+    cfg = synth.CONFIGS["tiny"]
+    m = zgpt.GPT(cfg)
+    with pytest.raises(_lib.ZgError):
+        m.prefill([np.zeros(cfg.context_size + 1, np.uint64)])
+    with pytest.raises(_lib.ZgError):
+        m.prefill([[cfg.vocab_size]])
+    m.close()
+    f = zgpt.GPT(cfg, weights_f32=True)
+    with pytest.raises(_lib.ZgError):
+        f.prefill([[1, 2, 3]])
+    f.close()

@@ -60,6 +60,7 @@ SIGNATURES = {
     "zg_gpt_weight_arena": (C.c_int, [vp, C.POINTER(vp), szp]),
     "zg_gpt_step_bytes": (C.c_int, [vp, sz, szp, szp]),
     "zg_gpt_forward": (C.c_int, [vp, sz, vp, sz, C.c_int, vp, sz]),
+    "zg_gpt_prefill": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, sz]),
     "zg_gpt_argmax": (C.c_int, [vp, vp, sz]),
     "zg_gpt_sample": (C.c_int, [vp, sz, vp, sz, C.c_float, vp, C.c_uint64, vp, vp, sz]),
     "zg_gpt_hidden": (C.c_int, [vp, vp, sz]),
@@ -71,7 +72,7 @@ SIGNATURES = {
 }
 
 # flags / slots of include/zgpt2.h
-GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16 = 0, 1, 2, 4
+GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL = 0, 1, 2, 4, 8
 BLOCK_SLOTS = ["ln_1_g", "ln_1_b", "c_attn_w", "c_attn_b", "c_proj_w", "c_proj_b",
                "ln_2_g", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b"]
 TOP_SLOTS = ["wte", "wpe", "ln_f_g", "ln_f_b"]

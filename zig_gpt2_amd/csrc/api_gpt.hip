@@ -11,6 +11,7 @@
 //                                                            contiguous [ctx, 64] slab, so no
 //                                                            per-step transpose (ops.zig:153,158)
 //   [ scratch: x q h4 attention partials logits argmax partials, control block, token buffers ]
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -41,6 +42,9 @@ struct zg_gpt {
     StepCtrl* ctrl;
     float *x, *q, *h4, *part, *logits, *part_val;
     int *part_idx, *prompt, *prompt_len, *forced, *cur_token, *out_tokens;
+    // whole-prompt (prefill) scratch, rows = batch * ctx: x fp32 [E], qkv fp32 [3E], split bf16 [kSplit E] and [kSplit 4E]
+    float *pf_x, *pf_qkv;
+    bf16_t *pf_a, *pf_h;
     int max_splits, lm_grid;
     // pinned host mirrors for small control traffic
     StepCtrl* h_ctrl;
@@ -113,6 +117,12 @@ void carve(zg_gpt* g, char* base) {
     g->forced = (int*)P(B * 4);
     g->cur_token = (int*)P(B * 4);
     g->out_tokens = (int*)P(B * C * 4);
+    if (g->wt == WT_BF16) {
+        g->pf_x = (float*)P(B * C * E * 4);
+        g->pf_qkv = (float*)P(B * C * 3 * E * 4);
+        g->pf_a = (bf16_t*)P(B * C * kSplit * E * 2);
+        g->pf_h = (bf16_t*)P(B * C * kSplit * 4 * E * 2);
+    }
     g->arena_bytes = (cv.off + 255) & ~(size_t)255;
 }
 
@@ -294,6 +304,34 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
         ZG_TRY(prof_mark(prof, 6, s));
     }
     return ZG_OK;
+}
+
+// Whole-prompt forward of positions 0..P-1 of every sequence (tokens in g->prompt): fills the KV caches
+// exactly as P calls of GPT.forward would (main.zig:331-334) and leaves the residual stream of all rows in
+// pf_x.  With `last_block_full` false the last Block stops after its cache append: nothing downstream of
+// it is needed when generation re-feeds the last prompt token (main.zig:337).
+int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
+    const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
+    const int B = (int)g->batch, M = (int)(g->batch * P), iE = (int)E;
+    ZG_TRY(launch_embed_prefill(g->prompt, (int)C, B, (int)P, g->wte, g->wpe, g->wt, iE, g->pf_x, s));
+    for (size_t l = 0; l < L; ++l) {
+        const zg_layer& y = g->layers[l];
+        ZG_TRY(launch_ln_split(g->pf_x, M, iE, y.ln_1_g, y.ln_1_b, 1e-5f, g->pf_a, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_F32, s));
+        ZG_TRY(launch_kv_scatter(g->pf_qkv, B, (int)P, iE, (int)H, (int)C, y.k_cache, y.v_cache, g->kv_f16, s));
+        if (l + 1 == L && !last_block_full) break;
+        ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, s));
+        ZG_TRY(launch_ln_split(g->pf_x, M, iE, y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, s));
+    }
+    return ZG_OK;
+}
+
+size_t prefill_min() {
+    static const long v = getenv("ZGPT2_PREFILL_MIN") ? atol(getenv("ZGPT2_PREFILL_MIN")) : 4;
+    return v > 0 ? (size_t)v : (size_t)-1;
 }
 
 void drop_graphs(zg_gpt* g) {
@@ -510,6 +548,43 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     return ZG_OK;
 }
 
+int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t n_tokens, int compute_logits,
+                   float* logits_out, size_t logits_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && tokens, ZG_ERR_ARG, "gpt_prefill: null argument");
+    ZG_REQUIRE(g->wt == WT_BF16, ZG_ERR_UNSUPPORTED, "gpt_prefill needs bf16 weights (handle created with ZG_GPT_WEIGHTS_F32)");
+    const size_t C = g->cfg.context_size, V = g->cfg.vocab_size, B = g->batch, E = g->cfg.n_embed;
+    ZG_REQUIRE(n_tokens >= 1 && n_tokens <= C && n_tokens <= token_stride, ZG_ERR_SHAPE,
+               "gpt_prefill: n_tokens %zu outside 1..%zu (stride %zu)", n_tokens, C, token_stride);
+    ZG_REQUIRE(!logits_out || (compute_logits && logits_len >= B * V), ZG_ERR_SHAPE,
+               "gpt_prefill: logits_out needs compute_logits and %zu elements", B * V);
+    hipStream_t s = ctx().stream;
+    ZG_HIP(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; ++b)
+        for (size_t i = 0; i < n_tokens; ++i) {
+            const size_t t = tokens[b * token_stride + i];
+            ZG_REQUIRE(t < V, ZG_ERR_SHAPE, "gpt_prefill: token %zu >= vocab %zu", t, V);
+            g->h_ints[b * C + i] = (int)t;
+        }
+    ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_TRY(enqueue_prefill(g, n_tokens, compute_logits != 0, s));
+    if (compute_logits) {  // ln_f + lm_head of each sequence's last position through the decode kernels
+        ZG_HIP(hipMemcpy2DAsync(g->x, E * 4, g->pf_x + (n_tokens - 1) * E, n_tokens * E * 4, E * 4, B,
+                                hipMemcpyDeviceToDevice, s));
+        g->h_ctrl->step = (int)n_tokens - 1;
+        g->h_ctrl->seq_len = (int)n_tokens;
+        g->h_ctrl->mode = 1;
+        g->h_ctrl->n_partials = g->lm_grid;
+        ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+        ZG_TRY(enqueue_lm_head(g, s));
+        if (logits_out)
+            ZG_HIP(hipMemcpyAsync(logits_out, g->logits, B * V * sizeof(float),
+                                  is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    }
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+
 int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && tokens_out && n_tokens == g->batch, ZG_ERR_ARG, "gpt_argmax: bad argument");
@@ -585,14 +660,23 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
         g->h_ints[B * C + b] = (int)np;
         if (np < min_prompt) min_prompt = np;
     }
-    g->h_ctrl->step = 0;
-    g->h_ctrl->seq_len = 0;
+    // The positions every sequence has a prompt token for go through the Blocks together (prefill); the
+    // rest of the loop is main.zig:330-338 one position at a time.
+    size_t first = 0;
+    if (g->wt == WT_BF16 && !(g->flags & ZG_GPT_NO_PREFILL) && min_prompt >= prefill_min())
+        first = min_prompt < n_steps ? min_prompt : n_steps;
+    g->h_ctrl->step = (int)first;
+    g->h_ctrl->seq_len = (int)first;
     g->h_ctrl->mode = 0;
     g->h_ctrl->n_partials = g->lm_grid;
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
-    for (size_t st = 0; st < n_steps; ++st) ZG_TRY(run_step(g, st >= min_prompt, st + 1, s));  // main.zig:330-338
+    if (first > 0) {
+        ZG_HIP(hipMemcpyAsync(g->out_tokens, g->prompt, B * C * sizeof(int), hipMemcpyDeviceToDevice, s));
+        ZG_TRY(enqueue_prefill(g, first, false, s));
+    }
+    for (size_t st = first; st < n_steps; ++st) ZG_TRY(run_step(g, st >= min_prompt, st + 1, s));
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
     g->steps_enqueued = n_steps;
     return ZG_OK;

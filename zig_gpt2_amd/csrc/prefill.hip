@@ -1,0 +1,436 @@
+// prefill.hip — whole-prompt forward: the reference feeds a prompt one token at a time through
+// GPT.forward (src/main.zig:331-334); here the n prompt positions of every sequence go through each Block
+// together, so the Linears become GEMMs on the matrix cores and attention becomes one causal pass.
+//
+// Numerics.  The decode path keeps activations in fp32 and weights in bf16 (exact products, fp32
+// accumulation).  To stay inside the same tolerance the GEMM A operand here is the fp32 activation split
+// into three bf16 terms, x = hi + mid + lo EXACTLY (24 = 8 + 8 + 8 mantissa bits; a two-term split leaves
+// 2^-18 |x| behind, which showed up as 2e-5 of the logit scale — outside the parity bar for logits that
+// happen to lie near zero), laid out [M][3K] = [hi | mid | lo]; the weight row is simply walked three
+// times (k index modulo K), so C = (hi + mid + lo) W^T accumulates in one fp32 MFMA chain.  Attention runs on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): no rounding of q, k,
+// v or the probabilities at all.
+//
+// Kernels
+//   embed_prefill      x[m] = wte[token[m]] + wpe[t]                         (src/main.zig:179-183)
+//   ln_split           a = split(LayerNorm(x))                               (src/ops.zig:82-104)
+//   prefill_gemm       128 x 128 x 64 tile, LDS-DMA two-stage ring (see gemm_mfma.hip), epilogues:
+//                        F32 store | fp32 residual add | GELU + split        (ops.zig:21-46, main.zig:136-145, :79-80)
+//   kv_scatter         K / V columns of the qkv rows -> head-major caches    (src/ops.zig:152-158)
+//   attn_prefill       causal softmax(q k^T / 8) v, flash style, transposed so that every per-query
+//                      statistic lives in one lane                           (src/ops.zig:249-307)
+#include "zg_kernels.h"
+
+namespace zg {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ bf16_t cvt_bf16(float x) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return (bf16_t)r;
+}
+// x = t[0] + t[1] + t[2] exactly: every residual is exactly representable and has 8 fewer significant bits
+__device__ __forceinline__ void split3(float x, bf16_t (&t)[3]) {
+    t[0] = cvt_bf16(x);
+    const float r1 = x - __uint_as_float((uint32_t)t[0] << 16);
+    t[1] = cvt_bf16(r1);
+    const float r2 = r1 - __uint_as_float((uint32_t)t[1] << 16);
+    t[2] = cvt_bf16(r2);
+}
+// four consecutive values -> 8 B into each of the kSplit planes (plane stride `plane` elements)
+__device__ __forceinline__ void store_split4(bf16_t* dst, size_t plane, f32x4 v) {
+    bf16_t t[4][3];
+    split3(v.x, t[0]);
+    split3(v.y, t[1]);
+    split3(v.z, t[2]);
+    split3(v.w, t[3]);
+#pragma unroll
+    for (int p = 0; p < kSplit; ++p) {
+        u32x2 w;
+        w.x = (uint32_t)t[0][p] | ((uint32_t)t[1][p] << 16);
+        w.y = (uint32_t)t[2][p] | ((uint32_t)t[3][p] << 16);
+        *reinterpret_cast<u32x2*>(dst + p * plane) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ embed
+__global__ __launch_bounds__(256) void embed_prefill_kernel(const int* __restrict__ tokens, int token_stride, int P,
+                                                            const void* __restrict__ wte, const void* __restrict__ wpe,
+                                                            int weight_type, int E, float* __restrict__ x) {
+    const int m = blockIdx.x, b = m / P, t = m % P;
+    const int tok = tokens[(size_t)b * token_stride + t];
+    for (int e = threadIdx.x * 4; e < E; e += 1024) {
+        f32x4 o;
+        if (weight_type == WT_BF16) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(wte) + (size_t)tok * E + e);
+            const u32x2 p = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(wpe) + (size_t)t * E + e);
+            o.x = bf16_lo(w.x) + bf16_lo(p.x);
+            o.y = bf16_hi(w.x) + bf16_hi(p.x);
+            o.z = bf16_lo(w.y) + bf16_lo(p.y);
+            o.w = bf16_hi(w.y) + bf16_hi(p.y);
+        } else {
+            o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(wte) + (size_t)tok * E + e) +
+                *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(wpe) + (size_t)t * E + e);
+        }
+        *reinterpret_cast<f32x4*>(x + (size_t)m * E + e) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm + split
+// One wave per row.  Same arithmetic as LayerNorm.forward: single pass sum / sum of squares,
+// std = sqrt(E[x^2] - mean^2 + eps), (x - mean) / std * g + b   (src/ops.zig:88-101).
+__global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__ x, int M, int E,
+                                                       const float* __restrict__ g, const float* __restrict__ bta,
+                                                       float eps, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * E;
+    float s = 0.0f, ss = 0.0f;
+    for (int e = lane * 4; e < E; e += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + e);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s = wave_allsum(s);
+    ss = wave_allsum(ss);
+    const float mean = s / (float)E;
+    const float sd = sqrtf(ss / (float)E - mean * mean + eps);
+    bf16_t* hi = out + (size_t)row * kSplit * E;
+    for (int e = lane * 4; e < E; e += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + e);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + e);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + e);
+        f32x4 o;
+        o.x = (v.x - mean) / sd * gg.x + bb.x;
+        o.y = (v.y - mean) / sd * gg.y + bb.y;
+        o.z = (v.z - mean) / sd * gg.z + bb.z;
+        o.w = (v.w - mean) / sd * gg.w + bb.w;
+        store_split4(hi + e, E, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GEMM
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK * 2;
+constexpr int kStageBytes = 2 * kTileBytes;
+constexpr int kLdsBytes = 2 * kStageBytes;  // 64 KiB: two stages; reused as the fp32 store staging area
+
+// rows beyond `rows` are clamped to the last valid row (loaded, never stored)
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int rows, int k0, char* lds_tile,
+                                           int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q;
+        const int row = piece * 8 + (lane >> 3);
+        const int pos = lane & 7;
+        const int chunk = pos ^ ((row >> 1) & 7);
+        const int grow = min(row0 + row, rows - 1);
+        const bf16_t* src = G + (size_t)grow * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
+    const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + off);
+}
+
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
+    const float arg = x * fmaf(x * x, k2, k1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+}
+
+// A: [M][3K] bf16 (hi | mid | lo), B: [N][K] bf16, bias [N].  C: fp32 [M][ldc] (PF_F32, PF_RESID) or bf16
+// [M][3N] split planes (PF_GELU_SPLIT).  N % 64 == 0, K % 64 == 0, any M.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                              const float* __restrict__ bias, void* __restrict__ C, int M,
+                                                              int N, int K, int ldc, int tiles_n, int n_tiles) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x;
+    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = K / BK, nt = kSplit * nk;  // every split plane of A walks the weight rows again
+    stage_tile(A, kSplit * K, m0, M, 0, lds, wave, lane);
+    stage_tile(B, K, n0, N, 0, lds + kTileBytes, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < nt; ++t) {
+        char* cur = lds + (t & 1) * kStageBytes;
+        if (t + 1 < nt) {
+            char* nxt = lds + ((t + 1) & 1) * kStageBytes;
+            const int tb = (t + 1) % nk;
+            stage_tile(A, kSplit * K, m0, M, (t + 1) * BK, nxt, wave, lane);
+            stage_tile(B, K, n0, N, tb * BK, nxt + kTileBytes, wave, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = read_frag(cur, wm * 64 + i * 32 + frow, kk * 2 + fk);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = read_frag(cur + kTileBytes, wn * 64 + j * 32 + frow, kk * 2 + fk);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+
+    // epilogue: the wave's 64 x 64 fp32 strip goes through LDS so that global accesses are 16-B row segments
+    const int nw = n0 + wn * 64;
+    if (nw >= N) return;  // N % 64 == 0: a strip is entirely inside or entirely outside
+    float* wtile = reinterpret_cast<float*>(lds + wave * (64 * 64 * 4));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + frow;
+        const float bv = bias ? bias[nw + col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                float v = acc[i][j][r] + bv;
+                if (EPI == PF_GELU_SPLIT) v = gelu_fast(v);
+                wtile[row * 64 + col] = v;
+            }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int c = it * 64 + lane;
+        const int row = c >> 4, cc = c & 15;
+        const int gm = m0 + wm * 64 + row;
+        if (gm >= M) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(wtile + row * 64 + cc * 4);
+        if (EPI == PF_GELU_SPLIT) {
+            store_split4(reinterpret_cast<bf16_t*>(C) + (size_t)gm * kSplit * N + nw + cc * 4, N, v);
+        } else {
+            float* dst = reinterpret_cast<float*>(C) + (size_t)gm * ldc + nw + cc * 4;
+            if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    }
+}
+
+template <int EPI>
+int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                          hipStream_t s) {
+    static bool raised = false;
+    if (!raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        raised = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    hipLaunchKernelGGL((prefill_gemm_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(256), kLdsBytes, s, A, B, bias, C, M, N, K,
+                       ldc, tiles_n, tiles_m * tiles_n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------ KV scatter
+// qkv row m = b P + t, columns [E, 2E) -> k_cache[b][h][t][d], [2E, 3E) -> v_cache (the cache rows the
+// reference appends at ops.zig:152,157; head-major here so that decode needs no transpose).
+template <typename KV>
+__global__ __launch_bounds__(256) void kv_scatter_kernel(const float* __restrict__ qkv, int P, int E, int H, int ctx,
+                                                         KV* __restrict__ kc, KV* __restrict__ vc, size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int e4 = (int)(i % (size_t)(E / 4)) * 4;
+    const size_t rest = i / (size_t)(E / 4);
+    const int which = (int)(rest & 1);
+    const size_t m = rest >> 1;
+    const int b = (int)(m / P), t = (int)(m % P), h = e4 / 64, d = e4 % 64;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + m * 3 * E + (which ? 2 * E : E) + e4);
+    KV* dst = (which ? vc : kc) + (((size_t)b * H + h) * ctx + t) * 64 + d;
+    dst[0] = (KV)v.x;
+    dst[1] = (KV)v.y;
+    dst[2] = (KV)v.z;
+    dst[3] = (KV)v.w;
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// Grid (ceil(P / 128), H, B), 4 waves; wave w owns the 32 queries q0 + 32 w .. + 31 of head h.  For each
+// 32-key tile (staged once per workgroup in LDS, padded rows) the wave computes
+//     S^T = K Q^T   32 x v_mfma_f32_32x32x2_f32   (A = K tile rows, B = the lane's own query, pre-scaled by 1/8)
+//     online softmax: the lane's 16 accumulator registers + its partner lane ^ 32 are one query's 32 scores
+//     O^T += V^T P^T  2 x 16 MFMAs               (B = the lane's probabilities, no transpose needed)
+// The k index of an MFMA step only has to agree between A and B, so step i of the second product pairs
+// the keys {(i & 3) + 8 (i >> 2) + 4 half}, exactly the rows the lane already holds.
+constexpr int kKS = 68, kVS = 72;  // padded LDS row strides (floats): conflict-free fragment reads
+
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out, int P,
+                                                           int E) {
+    __shared__ __attribute__((aligned(16))) float sK[32 * kKS];
+    __shared__ __attribute__((aligned(16))) float sV[32 * kVS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, hl = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int tq = q0 + wave * 32 + l32;
+    const size_t row0 = (size_t)b * P;
+    const int ld = 3 * E;
+
+    float qreg[32];
+    {
+        const float* qp = qkv + (row0 + min(tq, P - 1)) * ld + h * 64 + hl * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + c * 4);
+            qreg[c * 4 + 0] = v.x * 0.125f;  // 1 / sqrt(head_dim): exact scaling (ops.zig:275 applies it as sgemm alpha)
+            qreg[c * 4 + 1] = v.y * 0.125f;
+            qreg[c * 4 + 2] = v.z * 0.125f;
+            qreg[c * 4 + 3] = v.w * 0.125f;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
+    float mrun = -INFINITY, lrun = 0.0f;
+
+    const int last_q = min(q0 + 127, P - 1);
+    const int wave_last = q0 + wave * 32 + 31;
+    const int n_kt = last_q / 32 + 1;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 4, c4 = (idx & 15) * 4;
+            const float* src = qkv + (row0 + min(kt * 32 + r, P - 1)) * ld + h * 64 + c4;
+            *reinterpret_cast<f32x4*>(&sK[r * kKS + c4]) = *reinterpret_cast<const f32x4*>(src + E);
+            *reinterpret_cast<f32x4*>(&sV[r * kVS + c4]) = *reinterpret_cast<const f32x4*>(src + 2 * E);
+        }
+        __syncthreads();
+        if (kt * 32 > wave_last) continue;  // wave-uniform: every key of the tile lies in this wave's future
+
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(&sK[l32 * kKS + hl * 32 + c * 4]);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[c * 4 + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[c * 4 + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[c * 4 + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[c * 4 + 3], s, 0, 0, 0);
+        }
+        // s[r] = score of key kt*32 + (r & 3) + 8 (r >> 2) + 4 hl against query tq
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            s[r] = key <= tq ? s[r] : -INFINITY;  // causal: decode at position tq sees keys 0..tq
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        // rows of padding queries (tq >= P) and fully masked tiles keep mnew finite after tile 0 (key 0 <= tq)
+        const float corr = __expf(mrun - mnew);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - mnew);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * corr + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= corr;
+            o1[r] *= corr;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * hl;
+            const float v0 = sV[key * kVS + l32], v1 = sV[key * kVS + 32 + l32];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[i], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[i], o1, 0, 0, 0);
+        }
+    }
+    if (tq >= P) return;
+    // O^T: lane holds d = (r & 3) + 8 (r >> 2) + 4 hl (+ 32 for o1) of its query; softmax divides by the sum (ops.zig:239)
+    const float inv = 1.0f / lrun;
+    bf16_t* hi = out + (row0 + tq) * kSplit * E + h * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * hl;
+        f32x4 a, c;
+        a.x = o0[g * 4 + 0] * inv; a.y = o0[g * 4 + 1] * inv; a.z = o0[g * 4 + 2] * inv; a.w = o0[g * 4 + 3] * inv;
+        c.x = o1[g * 4 + 0] * inv; c.y = o1[g * 4 + 1] * inv; c.z = o1[g * 4 + 2] * inv; c.w = o1[g * 4 + 3] * inv;
+        store_split4(hi + d, E, a);
+        store_split4(hi + 32 + d, E, c);
+    }
+}
+
+}  // namespace
+
+int launch_embed_prefill(const int* tokens, int token_stride, int B, int P, const void* wte, const void* wpe,
+                         int weight_type, int E, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(embed_prefill_kernel, dim3(B * P), dim3(256), 0, s, tokens, token_stride, P, wte, wpe, weight_type,
+                       E, x);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_ln_split(const float* x, int M, int E, const float* g, const float* b, float eps, bf16_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(ln_split_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, E, g, b, eps, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
+                        hipStream_t s) {
+    ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
+    switch (epi) {
+        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, s);
+        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, s);
+        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, s);
+    }
+    ZG_REQUIRE(false, ZG_ERR_ARG, "prefill gemm: epilogue %d", epi);
+}
+
+int launch_kv_scatter(const float* qkv, int B, int P, int E, int H, int ctx, void* k_cache, void* v_cache, int kv_f16,
+                      hipStream_t s) {
+    const size_t total4 = (size_t)B * P * 2 * (E / 4);
+    const unsigned grid = (unsigned)((total4 + 255) / 256);
+    if (kv_f16)
+        hipLaunchKernelGGL(kv_scatter_kernel<_Float16>, dim3(grid), dim3(256), 0, s, qkv, P, E, H, ctx,
+                           reinterpret_cast<_Float16*>(k_cache), reinterpret_cast<_Float16*>(v_cache), total4);
+    else
+        hipLaunchKernelGGL(kv_scatter_kernel<float>, dim3(grid), dim3(256), 0, s, qkv, P, E, H, ctx,
+                           reinterpret_cast<float*>(k_cache), reinterpret_cast<float*>(v_cache), total4);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s) {
+    hipLaunchKernelGGL(attn_prefill_kernel, dim3((P + 127) / 128, H, B), dim3(256), 0, s, qkv, out, P, E);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+}  // namespace zg

@@ -16,11 +16,12 @@ from .synth import GPTConfig
 
 
 class GPT:
-    def __init__(self, config: GPTConfig, batch=1, weights_f32=False, use_graph=True, kv_f16=False):
+    def __init__(self, config: GPTConfig, batch=1, weights_f32=False, use_graph=True, kv_f16=False, prefill=True):
         self.config, self.batch = config, batch
         L = _lib.load()
         flags = (_lib.GPT_WEIGHTS_F32 if weights_f32 else 0) | (0 if use_graph else _lib.GPT_NO_GRAPH)
         flags |= _lib.GPT_KV_F16 if kv_f16 else 0
+        flags |= 0 if prefill else _lib.GPT_NO_PREFILL
         cfg = _lib.GptConfig(config.vocab_size, config.context_size, config.n_layer, config.n_heads, config.n_embed)
         h = C.c_void_p()
         check(L.zg_gpt_create(C.byref(h), C.byref(cfg), batch, flags))
@@ -69,6 +70,18 @@ class GPT:
             logits = np.empty((self.batch, self.config.vocab_size), np.float32)
         check(self._L.zg_gpt_forward(self.h, seq_len, ptr(tokens), tokens.size, int(compute_logits), ptr(logits),
                                      ops._n(logits)))
+        return logits
+
+    def prefill(self, tokens, compute_logits=True, want_logits=True):
+        """The prompt loop of generate (src/main.zig:331-334) as one pass: tokens [batch, n] are positions
+        0..n-1; returns the logits of position n-1 ([batch, V]) or None."""
+        tokens = np.ascontiguousarray(np.atleast_2d(tokens), dtype=np.uint64)
+        assert tokens.shape[0] == self.batch
+        logits = None
+        if compute_logits and want_logits:
+            logits = np.empty((self.batch, self.config.vocab_size), np.float32)
+        check(self._L.zg_gpt_prefill(self.h, ptr(tokens), tokens.shape[1], tokens.shape[1], int(compute_logits),
+                                     ptr(logits), ops._n(logits)))
         return logits
 
     def sample(self, seq_len, tokens, temp, uniforms=None, seed=0, want_probs=False):
