@@ -43,7 +43,8 @@ struct zg_gpt {
     float *x, *q, *h4, *part, *logits, *part_val;
     int *part_idx, *prompt, *prompt_len, *forced, *cur_token, *out_tokens;
     // whole-prompt (prefill) scratch, rows = batch * ctx: x fp32 [E], qkv fp32 [3E], split bf16 [kSplit E] and [kSplit 4E]
-    float *pf_x, *pf_qkv;
+    float *pf_x, *pf_qkv, *pf_ws;
+    size_t pf_ws_floats;
     bf16_t *pf_a, *pf_h;
     int max_splits, lm_grid;
     // pinned host mirrors for small control traffic
@@ -122,6 +123,8 @@ void carve(zg_gpt* g, char* base) {
         g->pf_qkv = (float*)P(B * C * 3 * E * 4);
         g->pf_a = (bf16_t*)P(B * C * kSplit * E * 2);
         g->pf_h = (bf16_t*)P(B * C * kSplit * 4 * E * 2);
+        g->pf_ws_floats = 16u << 20;  // 64 MiB of split-K partial sums
+        g->pf_ws = (float*)P(g->pf_ws_floats * 4);
     }
     g->arena_bytes = (cv.off + 255) & ~(size_t)255;
 }
@@ -317,14 +320,14 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
     for (size_t l = 0; l < L; ++l) {
         const zg_layer& y = g->layers[l];
         ZG_TRY(launch_ln_split(g->pf_x, M, iE, y.ln_1_g, y.ln_1_b, 1e-5f, g->pf_a, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_F32, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_F32, g->pf_ws, g->pf_ws_floats, s));
         ZG_TRY(launch_kv_scatter(g->pf_qkv, B, (int)P, iE, (int)H, (int)C, y.k_cache, y.v_cache, g->kv_f16, s));
         if (l + 1 == L && !last_block_full) break;
         ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws, g->pf_ws_floats, s));
         ZG_TRY(launch_ln_split(g->pf_x, M, iE, y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, g->pf_ws, g->pf_ws_floats, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws, g->pf_ws_floats, s));
     }
     return ZG_OK;
 }

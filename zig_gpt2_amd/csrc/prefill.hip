@@ -18,6 +18,8 @@
 //   kv_scatter         K / V columns of the qkv rows -> head-major caches    (src/ops.zig:152-158)
 //   attn_prefill       causal softmax(q k^T / 8) v, flash style, transposed so that every per-query
 //                      statistic lives in one lane                           (src/ops.zig:249-307)
+#include <stdlib.h>
+
 #include "zg_kernels.h"
 
 namespace zg {
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;
 constexpr int kStageBytes = 2 * kTileBytes;
-constexpr int kLdsBytes = 2 * kStageBytes;  // 64 KiB: two stages; reused as the fp32 store staging area
+constexpr int kStages = 4;                       // LDS ring depth: three K-steps of DMA in flight under the MFMAs
+constexpr int kLdsBytes = kStages * kStageBytes;  // 128 KiB; reused as the fp32 store staging area
 
 // rows beyond `rows` are clamped to the last valid row (loaded, never stored)
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int rows, int k0, char* lds_tile,
@@ -149,13 +152,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // A: [M][3K] bf16 (hi | mid | lo), B: [N][K] bf16, bias [N].  C: fp32 [M][ldc] (PF_F32, PF_RESID) or bf16
 // [M][3N] split planes (PF_GELU_SPLIT).  N % 64 == 0, K % 64 == 0, any M.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                               const float* __restrict__ bias, void* __restrict__ C, int M,
                                                               int N, int K, int ldc, int tiles_n, int n_tiles) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
+    const int sp = blockIdx.y, n_sp = gridDim.y;  // split-K slice (PF_PARTIAL only; otherwise 0 of 1)
     const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
@@ -169,21 +173,31 @@ __global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = K / BK, nt = kSplit * nk;  // every split plane of A walks the weight rows again
-    stage_tile(A, kSplit * K, m0, M, 0, lds, wave, lane);
-    stage_tile(B, K, n0, N, 0, lds + kTileBytes, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
+    // every split plane of A walks the weight rows again: kSplit * K / 64 steps; slice sp takes [t0, nt)
+    const int nk = K / BK, nt_all = kSplit * nk;
+    const int t0 = (int)((long)nt_all * sp / n_sp), nt = (int)((long)nt_all * (sp + 1) / n_sp);
+    // Ring of kStages slots, one raw s_barrier per K-step and counted vmcnt (8 LDS-DMA loads per wave per
+    // stage): at the top of step t the stages t .. t + kStages - 2 are in flight; waiting until at most
+    // 8 (kStages - 2) loads remain means this wave's pieces of stage t landed, the barrier makes that true
+    // for every wave and also says slot (t - 1) % kStages is no longer read, so it is refilled right away.
+    auto issue = [&](int t) {
+        char* slot = lds + ((t - t0) % kStages) * kStageBytes;
+        stage_tile(A, kSplit * K, m0, M, t * BK, slot, wave, lane);
+        stage_tile(B, K, n0, N, (t % nk) * BK, slot + kTileBytes, wave, lane);
+    };
+#pragma unroll
+    for (int i = 0; i < kStages - 1; ++i)
+        if (t0 + i < nt) issue(t0 + i);
 
     const int frow = lane & 31, fk = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        char* cur = lds + (t & 1) * kStageBytes;
-        if (t + 1 < nt) {
-            char* nxt = lds + ((t + 1) & 1) * kStageBytes;
-            const int tb = (t + 1) % nk;
-            stage_tile(A, kSplit * K, m0, M, (t + 1) * BK, nxt, wave, lane);
-            stage_tile(B, K, n0, N, tb * BK, nxt + kTileBytes, wave, lane);
-        }
+    for (int t = t0; t < nt; ++t) {
+        const int ahead = nt - 1 - t;  // stages after t that were already issued (capped below)
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x4f70);       // vmcnt(16)
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (t + kStages - 1 < nt) issue(t + kStages - 1);
+        const char* cur = lds + ((t - t0) % kStages) * kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 a[2], b[2];
@@ -197,9 +211,8 @@ __global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __re
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
     }
+    __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
 
     // epilogue: the wave's 64 x 64 fp32 strip goes through LDS so that global accesses are 16-B row segments
     const int nw = n0 + wn * 64;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = j * 32 + frow;
-        const float bv = bias ? bias[nw + col] : 0.0f;
+        const float bv = (EPI != PF_PARTIAL && bias) ? bias[nw + col] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -228,6 +241,8 @@ __global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __re
         f32x4 v = *reinterpret_cast<const f32x4*>(wtile + row * 64 + cc * 4);
         if (EPI == PF_GELU_SPLIT) {
             store_split4(reinterpret_cast<bf16_t*>(C) + (size_t)gm * kSplit * N + nw + cc * 4, N, v);
+        } else if (EPI == PF_PARTIAL) {  // C is the workspace [n_sp][M][N]
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ((size_t)sp * M + gm) * N + nw + cc * 4) = v;
         } else {
             float* dst = reinterpret_cast<float*>(C) + (size_t)gm * ldc + nw + cc * 4;
             if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
@@ -236,18 +251,59 @@ __global__ __launch_bounds__(256, 2) void prefill_gemm_kernel(const bf16_t* __re
     }
 }
 
+// Second half of a split-K GEMM: sum the slices in fixed order (deterministic), add bias, apply the epilogue.
+template <int EPI>
+__global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __restrict__ ws, int n_sp,
+                                                             const float* __restrict__ bias, void* __restrict__ C, int M,
+                                                             int N, int ldc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N / 4;
+    if (i >= (size_t)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+    for (int sp = 1; sp < n_sp; ++sp) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)sp * M + m) * N + n);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+    if (EPI == PF_GELU_SPLIT) {
+        v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
+        store_split4(reinterpret_cast<bf16_t*>(C) + (size_t)m * kSplit * N + n, N, v);
+    } else {
+        float* dst = reinterpret_cast<float*>(C) + (size_t)m * ldc + n;
+        if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+    }
+}
+
 template <int EPI>
 int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                          hipStream_t s) {
+                          float* ws, size_t ws_floats, hipStream_t s) {
     static bool raised = false;
     if (!raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<PF_PARTIAL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         raised = true;
     }
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    hipLaunchKernelGGL((prefill_gemm_kernel<EPI>), dim3(tiles_m * tiles_n), dim3(256), kLdsBytes, s, A, B, bias, C, M, N, K,
-                       ldc, tiles_n, tiles_m * tiles_n);
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    // Few output tiles (N = n_embed, or a short prompt): slice K so that about one workgroup per CU exists
+    // (the 128-KiB ring allows one), at least 6 K-steps per slice, partial sums through the workspace.
+    const int nt = kSplit * K / BK;
+    int n_sp = 256 / tiles;
+    if (n_sp > nt / 6) n_sp = nt / 6;
+    if (n_sp < 1) n_sp = 1;
+    while (n_sp > 1 && (size_t)n_sp * M * N > ws_floats) --n_sp;
+    static const int force = getenv("ZGPT2_PF_SPLITK") ? atoi(getenv("ZGPT2_PF_SPLITK")) : 0;
+    if (force > 0) n_sp = force;
+    if (n_sp <= 1 || !ws) {
+        hipLaunchKernelGGL((prefill_gemm_kernel<EPI>), dim3(tiles), dim3(256), kLdsBytes, s, A, B, bias, C, M, N, K, ldc,
+                           tiles_n, tiles);
+    } else {
+        hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL>), dim3(tiles, n_sp), dim3(256), kLdsBytes, s, A, B, bias,
+                           (void*)ws, M, N, K, ldc, tiles_n, tiles);
+        const size_t n = (size_t)M * (N / 4);
+        hipLaunchKernelGGL((prefill_reduce_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n_sp, bias, C,
+                           M, N, ldc);
+    }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -274,25 +330,53 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ attention
-// Grid (ceil(P / 128), H, B), 4 waves; wave w owns the 32 queries q0 + 32 w .. + 31 of head h.  For each
-// 32-key tile (staged once per workgroup in LDS, padded rows) the wave computes
+// Grid (ceil(nqb / 2), H, B), 4 waves, nqb = ceil(P / 32) query blocks.  A workgroup processes query
+// block x and then its mirror nqb - 1 - x, so causal work (x + 1 and nqb - x key tiles) is the same for
+// every workgroup wherever the dispatcher places it.  Within a block wave w takes the 32-key tiles w,
+// w + 4, ... up to the diagonal (split-KV, merged at the end): ~8 tiles per wave for a 1024-token prompt.  Tiles are wave-private (own LDS strip, no workgroup barrier in
+// the loop); the next tile's global loads are in flight while the current one is multiplied.  Per tile:
 //     S^T = K Q^T   32 x v_mfma_f32_32x32x2_f32   (A = K tile rows, B = the lane's own query, pre-scaled by 1/8)
 //     online softmax: the lane's 16 accumulator registers + its partner lane ^ 32 are one query's 32 scores
 //     O^T += V^T P^T  2 x 16 MFMAs               (B = the lane's probabilities, no transpose needed)
 // The k index of an MFMA step only has to agree between A and B, so step i of the second product pairs
-// the keys {(i & 3) + 8 (i >> 2) + 4 half}, exactly the rows the lane already holds.
+// the keys {(i & 3) + 8 (i >> 2) + 4 half}, exactly the rows the lane already holds.  Everything is
+// transposed (keys / head dims along the accumulator rows, the query along lanes) so that each per-query
+// statistic is one register of one lane.
 constexpr int kKS = 68, kVS = 72;  // padded LDS row strides (floats): conflict-free fragment reads
+constexpr int kAttnWaveLds = (32 * kKS + 32 * kVS) * 4;  // 17920 B per wave
+constexpr int kAttnLds = 4 * kAttnWaveLds;
 
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out, int P,
-                                                           int E) {
-    __shared__ __attribute__((aligned(16))) float sK[32 * kKS];
-    __shared__ __attribute__((aligned(16))) float sV[32 * kVS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+struct KvRegs {
+    f32x4 k[8], v[8];
+};
+
+__device__ __forceinline__ void kv_load(KvRegs& r, const float* __restrict__ qkv, size_t row0, int P, int ld, int E, int h,
+                                        int kt, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+        const float* src = qkv + (row0 + min(kt * 32 + row, P - 1)) * ld + h * 64 + c4;
+        r.k[j] = *reinterpret_cast<const f32x4*>(src + E);
+        r.v[j] = *reinterpret_cast<const f32x4*>(src + 2 * E);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out, int P,
+                                                              int E) {
+    extern __shared__ __attribute__((aligned(16))) char attn_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hl = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
-    const int tq = q0 + wave * 32 + l32;
+    const int b = blockIdx.z, h = blockIdx.y;
     const size_t row0 = (size_t)b * P;
     const int ld = 3 * E;
+    float* sK = reinterpret_cast<float*>(attn_lds + wave * kAttnWaveLds);
+    float* sV = sK + 32 * kKS;
+    const int nqb = (P + 31) >> 5;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int qb = pass ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    if (pass && qb == (int)blockIdx.x) break;  // odd block count: the middle block is its own mirror
+    const int tq = qb * 32 + l32;
 
     float qreg[32];
     {
@@ -311,20 +395,17 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
     float mrun = -INFINITY, lrun = 0.0f;
 
-    const int last_q = min(q0 + 127, P - 1);
-    const int wave_last = q0 + wave * 32 + 31;
-    const int n_kt = last_q / 32 + 1;
-    for (int kt = 0; kt < n_kt; ++kt) {
-        __syncthreads();
+    KvRegs nxt;
+    if (wave <= qb) kv_load(nxt, qkv, row0, P, ld, E, h, wave, lane);
+    for (int kt = wave; kt <= qb; kt += 4) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 256 * j, r = idx >> 4, c4 = (idx & 15) * 4;
-            const float* src = qkv + (row0 + min(kt * 32 + r, P - 1)) * ld + h * 64 + c4;
-            *reinterpret_cast<f32x4*>(&sK[r * kKS + c4]) = *reinterpret_cast<const f32x4*>(src + E);
-            *reinterpret_cast<f32x4*>(&sV[r * kVS + c4]) = *reinterpret_cast<const f32x4*>(src + 2 * E);
+        for (int j = 0; j < 8; ++j) {
+            const int idx = lane + 64 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<f32x4*>(&sK[row * kKS + c4]) = nxt.k[j];
+            *reinterpret_cast<f32x4*>(&sV[row * kVS + c4]) = nxt.v[j];
         }
-        __syncthreads();
-        if (kt * 32 > wave_last) continue;  // wave-uniform: every key of the tile lies in this wave's future
+        if (kt + 4 <= qb) kv_load(nxt, qkv, row0, P, ld, E, h, kt + 4, lane);
+        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
 
         f32x16 s;
 #pragma unroll
@@ -339,15 +420,17 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
         }
         // s[r] = score of key kt*32 + (r & 3) + 8 (r >> 2) + 4 hl against query tq
         float mx = -INFINITY;
+        if (kt == qb) {  // diagonal tile: causal mask (decode at position tq sees keys 0..tq); also hides rows >= P
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-            s[r] = key <= tq ? s[r] : -INFINITY;  // causal: decode at position tq sees keys 0..tq
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                s[r] = key <= tq ? s[r] : -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx);
-        // rows of padding queries (tq >= P) and fully masked tiles keep mnew finite after tile 0 (key 0 <= tq)
+        const float mnew = fmaxf(mrun, mx);  // finite: every tile has at least one visible key per query
         const float corr = __expf(mrun - mnew);
         float psum = 0.0f;
 #pragma unroll
@@ -370,8 +453,50 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[i], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[i], o1, 0, 0, 0);
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (tq >= P) return;
+
+    // merge the four key slices: waves 1..3 publish (m, l, O^T) in their own strip, wave 0 combines
+    float* strip = reinterpret_cast<float*>(attn_lds + wave * kAttnWaveLds);
+    if (wave > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<f32x4*>(&strip[(g * 64 + lane) * 4]) = f32x4{o0[g * 4], o0[g * 4 + 1], o0[g * 4 + 2], o0[g * 4 + 3]};
+            *reinterpret_cast<f32x4*>(&strip[1024 + (g * 64 + lane) * 4]) = f32x4{o1[g * 4], o1[g * 4 + 1], o1[g * 4 + 2], o1[g * 4 + 3]};
+        }
+        strip[2048 + lane] = mrun;
+        strip[2112 + lane] = lrun;
+    }
+    __syncthreads();
+    if (wave == 0 && tq < P) {
+    float mw[3], mall = mrun;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        mw[w - 1] = reinterpret_cast<const float*>(attn_lds + w * kAttnWaveLds)[2048 + lane];
+        mall = fmaxf(mall, mw[w - 1]);
+    }
+    {
+        const float c0 = __expf(mrun - mall);
+        lrun *= c0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= c0;
+            o1[r] *= c0;
+        }
+    }
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float* st = reinterpret_cast<const float*>(attn_lds + w * kAttnWaveLds);
+        const float cw = __expf(mw[w - 1] - mall);  // 0 for a slice that saw no tile (m = -inf, l = 0)
+        lrun += st[2112 + lane] * cw;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&st[(g * 64 + lane) * 4]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(&st[1024 + (g * 64 + lane) * 4]);
+            o0[g * 4 + 0] += a.x * cw; o0[g * 4 + 1] += a.y * cw; o0[g * 4 + 2] += a.z * cw; o0[g * 4 + 3] += a.w * cw;
+            o1[g * 4 + 0] += c.x * cw; o1[g * 4 + 1] += c.y * cw; o1[g * 4 + 2] += c.z * cw; o1[g * 4 + 3] += c.w * cw;
+        }
+    }
     // O^T: lane holds d = (r & 3) + 8 (r >> 2) + 4 hl (+ 32 for o1) of its query; softmax divides by the sum (ops.zig:239)
     const float inv = 1.0f / lrun;
     bf16_t* hi = out + (row0 + tq) * kSplit * E + h * 64;
@@ -384,6 +509,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restri
         store_split4(hi + d, E, a);
         store_split4(hi + 32 + d, E, c);
     }
+    }
+    __syncthreads();  // strips are free again for the mirror block's tiles
+  }
 }
 
 }  // namespace
@@ -403,12 +531,12 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 }
 
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
-                        hipStream_t s) {
+                        float* ws, size_t ws_floats, hipStream_t s) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
     switch (epi) {
-        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, s);
-        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, s);
-        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, s);
+        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
+        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
+        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
     }
     ZG_REQUIRE(false, ZG_ERR_ARG, "prefill gemm: epilogue %d", epi);
 }
@@ -428,7 +556,14 @@ int launch_kv_scatter(const float* qkv, int B, int P, int E, int H, int ctx, voi
 }
 
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s) {
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3((P + 127) / 128, H, B), dim3(256), 0, s, qkv, out, P, E);
+    static bool raised = false;
+    if (!raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds));
+        raised = true;
+    }
+    const int nqb = (P + 31) / 32;
+    hipLaunchKernelGGL(attn_prefill_kernel, dim3((nqb + 1) / 2, H, B), dim3(256), kAttnLds, s, qkv, out, P, E);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
