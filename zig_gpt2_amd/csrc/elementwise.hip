@@ -130,13 +130,14 @@ __device__ __forceinline__ float load_emb(const void* w, int wt, size_t off) {
 // Latency-bound: the argmax partials of the previous step are fetched speculatively together with
 // the control words (one memory round trip), one wave per sequence; only the wte row depends on
 // the chosen token (second round trip).
-__global__ __launch_bounds__(256) void embed_step_kernel(const EmbedArgs a) {
+__global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
     __shared__ int s_tok[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = a.ctrl->step;
     const int mode = a.ctrl->mode;
     const int npart = a.n_partials;
-    for (int b = wave; b < a.batch; b += 4) {
+    const int n_waves = blockDim.x >> 6;
+    for (int b = wave; b < a.batch; b += n_waves) {
         // speculative fetch of this sequence's partial maxima (valid memory whether or not needed)
         float bv = -3.0e38f;
         int bi = 0x7fffffff;
@@ -335,7 +336,7 @@ int launch_sample(float* logits, int batch, int vocab, float temp, const float* 
 }
 
 int launch_embed_step(const EmbedArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(embed_step_kernel, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(embed_step_kernel, dim3(1), dim3(a.batch > 4 ? 512 : 256), 0, s, a);  // one wave per sequence
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

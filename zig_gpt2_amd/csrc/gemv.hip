@@ -646,48 +646,50 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const GemvArgs a) {
 //               in fp32, so the result has fp32-FMA quality (the north_star 1e-3 bound would not
 //               survive a plain bf16 rounding of the activations: 2^-9 per element);
 //   D          = 16 (batch, 8 used) x 16 (weight rows); lane l holds n = l & 15, m = 4 (l >> 4) + r.
-// A workgroup owns a range of 16-row tiles; its 4 waves split K (each takes every 4th 32-k step) and
-// combine their partial tiles through LDS; wave 0 runs the fused epilogue.
+// A workgroup owns a range of 16-row tiles; its waves split K (wave w takes the 32-k steps w, w + NW, ...)
+// and combine their partial tiles through LDS; wave 0 runs the fused epilogue.
 // ================================================================================================
 typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float mf_f32x4;
 
 constexpr int kMfmaRows = 8;  // batch rows held in LDS (rows 8..15 of the MFMA tile alias rows 0..7)
 
-__device__ __forceinline__ void split3(float x, bf16_t& hi, bf16_t& mid, bf16_t& lo) {
-    hi = f32_to_bf16_rne(x);
-    const float r1 = x - __uint_as_float((uint32_t)hi << 16);
-    mid = f32_to_bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float((uint32_t)mid << 16);
-    lo = f32_to_bf16_rne(r2);
-}
-
 // planes: [3][kMfmaRows][S] bytes, S = 2 K + 16 (the 16-B pad spreads the rows over the LDS banks)
 __device__ __forceinline__ void store_split4(char* planes, int S, int m, int k, f32x4 v) {
-    bf16_t h[4], md[4], l[4];
-    split3(v.x, h[0], md[0], l[0]);
-    split3(v.y, h[1], md[1], l[1]);
-    split3(v.z, h[2], md[2], l[2]);
-    split3(v.w, h[3], md[3], l[3]);
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split3_pk(v.x, v.y, h0, m0, l0);
+    split3_pk(v.z, v.w, h1, m1, l1);
+    const u32x2 h = {h0, h1}, md = {m0, m1}, l = {l0, l1};
     const size_t off = (size_t)m * S + (size_t)k * 2;
     const size_t plane = (size_t)kMfmaRows * S;
-    *reinterpret_cast<u32x2*>(planes + off) = u32x2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
-    *reinterpret_cast<u32x2*>(planes + plane + off) = u32x2{(uint32_t)md[0] | ((uint32_t)md[1] << 16), (uint32_t)md[2] | ((uint32_t)md[3] << 16)};
-    *reinterpret_cast<u32x2*>(planes + 2 * plane + off) = u32x2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+    *reinterpret_cast<u32x2*>(planes + off) = h;
+    *reinterpret_cast<u32x2*>(planes + plane + off) = md;
+    *reinterpret_cast<u32x2*>(planes + 2 * plane + off) = l;
 }
 
-template <int KS, bool ARGMAX, bool SPLITK>  // KS = 32-k steps per wave: K/32 (whole K) or K/32/4 (split K)
-__global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin,
-                                                        int N, int K, int M, int tiles_per_wg, int prologue,
-                                                        int epilogue, const float* __restrict__ ln_g,
-                                                        const float* __restrict__ ln_b, const GemvArgs a) {
+// KS = 32-k steps per wave (K / 32 split over the NW waves of the workgroup).  NW = 16 (1024 threads, one
+// workgroup per CU) for the per-layer Linears, NW = 4 for the vocabulary-wide lm_head (many tiles per
+// workgroup, three workgroups per CU).
+//
+// Prologue layout: the 8 input rows are dealt to the waves — NW = 16: wave w owns half (w >> 3) of row
+// w & 7; NW = 4: wave w owns rows w and w + 4 — so a lane touches at most JT float4 per row, LayerNorm
+// needs two wave reductions per row and one partial-sum exchange through LDS, and the three-plane split
+// is 8..24 elements per lane.  (The first version gave every thread a column slice of ALL rows: 16 wave
+// reductions and 64 elements of split per thread made the prologue 9k of the kernel's 15k cycles.)
+template <int KS, int NW, bool ARGMAX>
+__global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin,
+                                                            int N, int K, int M, int tiles_per_wg, int prologue,
+                                                            int epilogue, const float* __restrict__ ln_g,
+                                                            const float* __restrict__ ln_b, const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_mf[];
+    ZG_STAMP_DECL();
+    ZG_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq = K >> 2, nsteps = K >> 5;
     const int S = 2 * K + 16;
-    char* planes = smem_mf;                                             // [3][8][S]
-    float* red = reinterpret_cast<float*>(smem_mf + (size_t)3 * kMfmaRows * S);  // LN stats, then partial tiles
+    char* planes = smem_mf;                                                       // [3][8][S]
+    float* red = reinterpret_cast<float*>(smem_mf + (size_t)3 * kMfmaRows * S);  // LN partial sums, then partial tiles
     const int ntiles = (N + 15) >> 4;
     const int tile_begin = blockIdx.x * tiles_per_wg;
     const int tile_end = min(tile_begin + tiles_per_wg, ntiles);
@@ -696,103 +698,127 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     // ---- 0. first tile's weight fragments: independent of everything else
     u32x4 wq[KS];
     auto load_tile = [&](int tile) {
-        const bf16_t* wp = W + (size_t)min(tile * 16 + brow, N - 1) * K + bq * 8;
+        const bf16_t* wp = W + (size_t)min(min(tile, ntiles - 1) * 16 + brow, N - 1) * K + bq * 8;
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-            const int st = min(SPLITK ? wave + 4 * i : i, nsteps - 1);  // surplus steps re-read the last one (weight 0 below)
+            const int st = min(wave + NW * i, nsteps - 1);  // surplus steps re-read the last one (weight 0 below)
             wq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + st * 32));
         }
     };
-    // SPLITK: the 4 waves share each tile and split K.  Otherwise (very wide matrices: lm_head) every wave
-    // owns whole tiles t, t+4, ...: no per-tile barrier, four epilogues in parallel.
-    const int tile_first = SPLITK ? tile_begin : tile_begin + wave, tile_step = SPLITK ? 1 : 4;
-    load_tile(min(tile_first, ntiles - 1));
+    load_tile(tile_begin);
     const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    ZG_STAMP(1);
+    // bias / residual of the FIRST tile are fetched here, next to the weights, instead of one more
+    // dependent L2 round trip inside the epilogue
+    float pre_bias = 0.0f, pre_res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (wave == 0) {
+        const int n = min(min(tile_begin, ntiles - 1) * 16 + brow, N - 1);
+        if (a.bias) pre_bias = a.bias[n];
+        if (epilogue == EPI_RESIDUAL)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre_res[r] = a.resid[(size_t)min(bq * 4 + r, M - 1) * a.resid_stride + n];
+    }
 
     // ---- 1. prologue: transformed input rows -> three bf16 planes in LDS (once per workgroup)
-    if (prologue == PRO_LAYERNORM) {
-        float* stat = red;  // [4 waves][8 rows][2]
-        f32x4 v[kMfmaRows][2], g4[2], b4[2];
+    constexpr int RPW = NW >= 8 ? 1 : kMfmaRows / NW;    // rows per wave
+    constexpr int PARTS = NW >= 8 ? NW / kMfmaRows : 1;  // waves sharing a row
+    constexpr int JT = NW >= 8 ? KS : (KS + 1) / 2;      // float4 per lane per row (covers K <= 32 KS NW)
+    const int part = NW >= 8 ? wave >> 3 : 0;
+    const int cols = (nq + PARTS - 1) / PARTS;           // float4 columns per wave
+    const int c0 = part * cols, c1 = min(nq, c0 + cols);
+    int cidx[JT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ic = min(tid + 256 * j, nq - 1);
-            g4[j] = reinterpret_cast<const f32x4*>(ln_g)[ic];
-            b4[j] = reinterpret_cast<const f32x4*>(ln_b)[ic];
+    for (int t = 0; t < JT; ++t) cidx[t] = c0 + lane + 64 * t;
+    auto row_of = [&](int j) { return NW >= 8 ? (wave & 7) : wave + NW * j; };
+
+    constexpr bool kHasLn = NW == 4 || NW * KS * 32 <= 2048;  // fused LayerNorm is dispatched only for K <= 2048
+    if (kHasLn && prologue == PRO_LAYERNORM) {
+        f32x4 v[RPW][JT], g4[JT], b4[JT];
 #pragma unroll
-            for (int m = 0; m < kMfmaRows; ++m)
-                v[m][j] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[ic];
+        for (int t = 0; t < JT; ++t) {
+            const int ic = min(cidx[t], nq - 1);
+            g4[t] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+            b4[t] = reinterpret_cast<const f32x4*>(ln_b)[ic];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                v[j][t] = reinterpret_cast<const f32x4*>(xin + (size_t)min(row_of(j), M - 1) * a.x_stride)[ic];
         }
+        float* stat = red;  // [8 rows][PARTS][2]
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int m = 0; m < kMfmaRows; ++m)
-                if (tid + 256 * j >= nq || m >= M) v[m][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int m = 0; m < kMfmaRows; ++m) {
+        for (int j = 0; j < RPW; ++j) {
             float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                t1 += (v[m][j].x + v[m][j].y) + (v[m][j].z + v[m][j].w);
-                t2 = fmaf(v[m][j].x, v[m][j].x, fmaf(v[m][j].y, v[m][j].y, fmaf(v[m][j].z, v[m][j].z, fmaf(v[m][j].w, v[m][j].w, t2))));
+            for (int t = 0; t < JT; ++t) {
+                if (cidx[t] >= c1) v[j][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                t1 += (v[j][t].x + v[j][t].y) + (v[j][t].z + v[j][t].w);
+                t2 = fmaf(v[j][t].x, v[j][t].x, fmaf(v[j][t].y, v[j][t].y, fmaf(v[j][t].z, v[j][t].z, fmaf(v[j][t].w, v[j][t].w, t2))));
             }
             t1 = wave_allsum(t1);
             t2 = wave_allsum(t2);
             if (lane == 0) {
-                stat[(wave * kMfmaRows + m) * 2] = t1;
-                stat[(wave * kMfmaRows + m) * 2 + 1] = t2;
+                stat[(row_of(j) * PARTS + part) * 2] = t1;
+                stat[(row_of(j) * PARTS + part) * 2 + 1] = t2;
             }
         }
         __syncthreads();
+        ZG_STAMP(2);
         const float inv_k = 1.0f / (float)K;
 #pragma unroll
-        for (int m = 0; m < kMfmaRows; ++m) {
+        for (int j = 0; j < RPW; ++j) {
+            const int m = row_of(j);
             float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                s1 += stat[(w * kMfmaRows + m) * 2];
-                s2 += stat[(w * kMfmaRows + m) * 2 + 1];
+            for (int p = 0; p < PARTS; ++p) {
+                s1 += stat[(m * PARTS + p) * 2];
+                s2 += stat[(m * PARTS + p) * 2 + 1];
             }
             const float mean = s1 * inv_k;
             const float rstd = __builtin_amdgcn_rsqf(s2 * inv_k - mean * mean + a.eps);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = tid + 256 * j;
-                if (i < nq) {
+            for (int t = 0; t < JT; ++t) {
+                if (cidx[t] < c1) {
                     f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     if (m < M) {
-                        o.x = fmaf((v[m][j].x - mean) * rstd, g4[j].x, b4[j].x);
-                        o.y = fmaf((v[m][j].y - mean) * rstd, g4[j].y, b4[j].y);
-                        o.z = fmaf((v[m][j].z - mean) * rstd, g4[j].z, b4[j].z);
-                        o.w = fmaf((v[m][j].w - mean) * rstd, g4[j].w, b4[j].w);
+                        o.x = fmaf((v[j][t].x - mean) * rstd, g4[t].x, b4[t].x);
+                        o.y = fmaf((v[j][t].y - mean) * rstd, g4[t].y, b4[t].y);
+                        o.z = fmaf((v[j][t].z - mean) * rstd, g4[t].z, b4[t].z);
+                        o.w = fmaf((v[j][t].w - mean) * rstd, g4[t].w, b4[t].w);
                     }
-                    store_split4(planes, S, m, i * 4, o);
+                    store_split4(planes, S, m, cidx[t] * 4, o);
                 }
             }
         }
     } else if (prologue == PRO_ATTN_MERGE) {
         const int t_hi = a.t_hi > 0 ? a.t_hi : T;
         const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
-        for (int i = tid; i < nq; i += 256) {
-            f32x4 o[kMfmaRows];
 #pragma unroll
-            for (int m = 0; m < kMfmaRows; ++m) o[m] = merge_attn4(a, min(m, M - 1), i * 4, nsplit);
+        for (int j = 0; j < RPW; ++j) {
+            const int m = row_of(j);
 #pragma unroll
-            for (int m = 0; m < kMfmaRows; ++m)
-                store_split4(planes, S, m, i * 4, (m < M) ? o[m] : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            for (int t = 0; t < JT; ++t) {  // one merge at a time: each already has 4 x 6 loads in flight
+                if (cidx[t] >= c1) continue;
+                const f32x4 o = merge_attn4(a, min(m, M - 1), cidx[t] * 4, nsplit);
+                store_split4(planes, S, m, cidx[t] * 4, (m < M) ? o : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            }
         }
     } else {
-        for (int i = tid; i < nq; i += 256) {
-            f32x4 o[kMfmaRows];
 #pragma unroll
-            for (int m = 0; m < kMfmaRows; ++m) o[m] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[i];
+        for (int j = 0; j < RPW; ++j) {
+            const int m = row_of(j);
+            f32x4 o[JT];
 #pragma unroll
-            for (int m = 0; m < kMfmaRows; ++m)
-                store_split4(planes, S, m, i * 4, (m < M) ? o[m] : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            for (int t = 0; t < JT; ++t)
+                o[t] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[min(cidx[t], nq - 1)];
+#pragma unroll
+            for (int t = 0; t < JT; ++t)
+                if (cidx[t] < c1) store_split4(planes, S, m, cidx[t] * 4, (m < M) ? o[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
         }
     }
     __syncthreads();
+    ZG_STAMP(3);
 
-    // ---- 2. tiles
+    // ---- 2. tiles: the NW waves split K (wave w takes the 32-k steps w, w + NW, ...) and combine their
+    // partial tiles through LDS; wave 0 runs the fused epilogue while the others start the next tile
     Best best[ARGMAX ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < (ARGMAX ? 4 : 1); ++r) {
@@ -802,13 +828,13 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
     const int pos = T - 1;
     const size_t plane = (size_t)kMfmaRows * S;
     const char* arow = planes + (size_t)(lane & 7) * S + bq * 16;  // A fragment: batch row (lane & 15) & 7
-    float* part = red + 4 * kMfmaRows * 2;                         // [2 buffers][4 waves][64 lanes][4]
+    float* partial = red + 64;                                     // [2 buffers][NW waves][64 lanes][4]
     int buf = 0;
-    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
         mf_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
-            const int st = SPLITK ? wave + 4 * i : i;
+            const int st = wave + NW * i;
             const int stc = min(st, nsteps - 1);
             u32x4 wv = wq[i];
             if (st >= nsteps) wv = u32x4{0u, 0u, 0u, 0u};
@@ -820,43 +846,45 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, b, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
         }
-        if (tile + tile_step < tile_end) load_tile(tile + tile_step);  // next tile's weights fly under the epilogue
-        if (SPLITK) {
-            float* mine = part + ((buf * 4 + wave) * 64 + lane) * 4;
-            *reinterpret_cast<mf_f32x4*>(mine) = acc;
-            __syncthreads();
-        }
-        if ((!SPLITK || wave == 0) && lane < 32) {  // lanes 0..31 hold batch rows 0..7
-            mf_f32x4 sum = acc;
-            if (SPLITK) {
+        if (tile == tile_begin) ZG_STAMP(4);
+        if (tile + 1 < tile_end) load_tile(tile + 1);  // next tile's weights fly under the epilogue
+        *reinterpret_cast<mf_f32x4*>(partial + ((buf * NW + wave) * 64 + lane) * 4) = acc;
+        __syncthreads();
+        if (tile == tile_begin) ZG_STAMP(5);
+        if (wave == 0) {
+            // lanes 32..63 hold duplicates of lanes 0..31 (tile rows 8..15 alias the batch rows 0..7): with 16
+            // waves each half of the wave sums 8 of the partial tiles, one cross-half exchange adds the two
+            constexpr int NSUM = NW == 16 ? 8 : NW;
+            const int w0 = NW == 16 ? (lane >> 5) * 8 : 0;
+            mf_f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int w = 1; w < 4; ++w) {
-                    const mf_f32x4 o = *reinterpret_cast<const mf_f32x4*>(part + ((buf * 4 + w) * 64 + lane) * 4);
-                    sum += o;
-                }
+            for (int w = 0; w < NSUM; ++w) sum += *reinterpret_cast<const mf_f32x4*>(partial + ((buf * NW + w0 + w) * 64 + lane) * 4);
+            if (NW == 16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], 32, 64);
             }
             const int n = tile * 16 + brow;
-            if (n < N) {
-                const float bias_n = a.bias ? a.bias[n] : 0.0f;
+            if (lane < 32 && n < N) {  // lanes 0..31 hold batch rows 0..7
+                const bool first = tile == tile_begin;
+                const float bias_n = first ? pre_bias : (a.bias ? a.bias[n] : 0.0f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = bq * 4 + r;
                     if (m < M) {
-                        const float res = (epilogue == EPI_RESIDUAL) ? a.resid[(size_t)m * a.resid_stride + n] : 0.0f;
+                        const float res = first ? pre_res[r]
+                                                : ((epilogue == EPI_RESIDUAL) ? a.resid[(size_t)m * a.resid_stride + n] : 0.0f);
                         epilogue_row(a, m, n, sum[r], bias_n, res, pos, best[ARGMAX ? r : 0]);
                     }
                 }
             }
         }
+        if (tile == tile_begin) ZG_STAMP(6);
         buf ^= 1;
     }
+    ZG_STAMP(7);
 
-    // ---- 3. argmax partials: rows m = 4 bq + r live in the 16 lanes of DPP row bq (of wave 0 when K is
-    // split; of every wave otherwise, combined through LDS)
+    // ---- 3. argmax partials: rows m = 4 bq + r live in the 16 lanes of DPP row bq of wave 0
     if constexpr (ARGMAX) {
-        float* s_val = part;                                   // [4 waves][8 rows]
-        int* s_idx = reinterpret_cast<int*>(part + 32);
-        if (!SPLITK) __syncthreads();                          // tiles done: `part` is free
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             Best b = best[r];
@@ -868,66 +896,50 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const bf16_t* __restrict
                 b = better(b, o);
             }
             const int m = bq * 4 + r;
-            if (brow == 0 && lane < 32) {
-                if (SPLITK) {
-                    if (wave == 0 && m < M) {
-                        a.part_val[(size_t)m * gridDim.x + blockIdx.x] = b.val;
-                        a.part_idx[(size_t)m * gridDim.x + blockIdx.x] = b.idx;
-                    }
-                } else {
-                    s_val[wave * 8 + m] = b.val;
-                    s_idx[wave * 8 + m] = b.idx;
-                }
-            }
-        }
-        if (!SPLITK) {
-            __syncthreads();
-            if (tid < kMfmaRows && tid < M) {
-                Best b;
-                b.val = s_val[tid];
-                b.idx = s_idx[tid];
-                for (int w = 1; w < 4; ++w) {
-                    Best o;
-                    o.val = s_val[w * 8 + tid];
-                    o.idx = s_idx[w * 8 + tid];
-                    b = better(b, o);
-                }
-                a.part_val[(size_t)tid * gridDim.x + blockIdx.x] = b.val;
-                a.part_idx[(size_t)tid * gridDim.x + blockIdx.x] = b.idx;
+            if (wave == 0 && brow == 0 && lane < 32 && m < M) {
+                a.part_val[(size_t)m * gridDim.x + blockIdx.x] = b.val;
+                a.part_idx[(size_t)m * gridDim.x + blockIdx.x] = b.idx;
             }
         }
     }
+    ZG_STAMP_FLUSH();
 }
 
-inline size_t gemv_mfma_lds(int K) {
-    return (size_t)3 * kMfmaRows * (2 * K + 16) + (4 * kMfmaRows * 2 + 2 * 4 * 64 * 4) * sizeof(float);
+inline int gemv_mfma_waves(const GemvArgs& a) { return a.epilogue == EPI_ARGMAX ? 4 : 16; }
+
+inline size_t gemv_mfma_lds(int K, int nw) {
+    return (size_t)3 * kMfmaRows * (2 * K + 16) + (64 + 2 * nw * 64 * 4) * sizeof(float);
 }
 
-template <int KS, bool ARGMAX, bool SPLITK>
+template <int KS, int NW, bool ARGMAX>
 int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
-    const size_t lds = gemv_mfma_lds(a.K);
+    const size_t lds = gemv_mfma_lds(a.K, NW);
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, ARGMAX, SPLITK>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((gemv_mfma_kernel<KS, ARGMAX, SPLITK>), dim3(grid), dim3(256), lds, s,
+    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX>), dim3(grid), dim3(NW * 64), lds, s,
                        reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K, a.M, a.rows_per_wave, a.prologue,
                        a.epilogue, a.ln_g, a.ln_b, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
-// Only the split-K form is dispatched: the whole-K form (SPLITK = false: every wave owns whole tiles, no
-// per-tile barrier) measured slower on lm_head at M = 8 (49.6 vs 27.7 us per launch).
 int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
-    const bool am = a.epilogue == EPI_ARGMAX;
-    const int ks = (a.K / 32 + 3) / 4;
-    if (ks <= 3) return am ? launch_mfma_inst<3, true, true>(a, grid, s) : launch_mfma_inst<3, false, true>(a, grid, s);
-    if (ks <= 6) return am ? launch_mfma_inst<6, true, true>(a, grid, s) : launch_mfma_inst<6, false, true>(a, grid, s);
-    if (ks <= 13) return am ? launch_mfma_inst<13, true, true>(a, grid, s) : launch_mfma_inst<13, false, true>(a, grid, s);
-    return am ? launch_mfma_inst<24, true, true>(a, grid, s) : launch_mfma_inst<24, false, true>(a, grid, s);
+    const int steps = a.K / 32;
+    if (a.epilogue == EPI_ARGMAX) {  // lm_head: 4 waves
+        const int ks = (steps + 3) / 4;
+        if (ks <= 3) return launch_mfma_inst<3, 4, true>(a, grid, s);
+        if (ks <= 6) return launch_mfma_inst<6, 4, true>(a, grid, s);
+        if (ks <= 13) return launch_mfma_inst<13, 4, true>(a, grid, s);
+        return launch_mfma_inst<24, 4, true>(a, grid, s);
+    }
+    const int ks = (steps + 15) / 16;
+    if (ks <= 2) return launch_mfma_inst<2, 16, false>(a, grid, s);
+    if (ks <= 4) return launch_mfma_inst<4, 16, false>(a, grid, s);
+    return launch_mfma_inst<6, 16, false>(a, grid, s);
 }
 
 template <typename WT, int MT, int LPR, int CPL, bool ARGMAX>
@@ -1007,7 +1019,7 @@ bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
     if (off || weight_type != WT_BF16 || a.M < 2 || a.M > kMfmaRows) return false;
     if (a.K % 32 != 0 || a.K / 32 < 4 || a.K / 32 > 96) return false;
     if (a.prologue == PRO_LAYERNORM && a.K > 2048) return false;
-    return gemv_mfma_lds(a.K) <= 160 * 1024;
+    return gemv_mfma_lds(a.K, gemv_mfma_waves(a)) <= 160 * 1024;
 }
 
 int gemv_plan(GemvArgs& a, int weight_type) {

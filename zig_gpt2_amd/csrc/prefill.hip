@@ -36,28 +36,14 @@ __device__ __forceinline__ bf16_t cvt_bf16(float x) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
     return (bf16_t)r;
 }
-// x = t[0] + t[1] + t[2] exactly: every residual is exactly representable and has 8 fewer significant bits
-__device__ __forceinline__ void split3(float x, bf16_t (&t)[3]) {
-    t[0] = cvt_bf16(x);
-    const float r1 = x - __uint_as_float((uint32_t)t[0] << 16);
-    t[1] = cvt_bf16(r1);
-    const float r2 = r1 - __uint_as_float((uint32_t)t[1] << 16);
-    t[2] = cvt_bf16(r2);
-}
-// four consecutive values -> 8 B into each of the kSplit planes (plane stride `plane` elements)
+// four consecutive values -> 8 B into each of the kSplit planes (plane stride `plane` elements); the split
+// is exact: x = hi + mid + lo (zg_common.h split3_pk)
 __device__ __forceinline__ void store_split4(bf16_t* dst, size_t plane, f32x4 v) {
-    bf16_t t[4][3];
-    split3(v.x, t[0]);
-    split3(v.y, t[1]);
-    split3(v.z, t[2]);
-    split3(v.w, t[3]);
+    uint32_t a[3], b[3];
+    split3_pk(v.x, v.y, a[0], a[1], a[2]);
+    split3_pk(v.z, v.w, b[0], b[1], b[2]);
 #pragma unroll
-    for (int p = 0; p < kSplit; ++p) {
-        u32x2 w;
-        w.x = (uint32_t)t[0][p] | ((uint32_t)t[1][p] << 16);
-        w.y = (uint32_t)t[2][p] | ((uint32_t)t[3][p] << 16);
-        *reinterpret_cast<u32x2*>(dst + p * plane) = w;
-    }
+    for (int p = 0; p < kSplit; ++p) *reinterpret_cast<u32x2*>(dst + p * plane) = u32x2{a[p], b[p]};
 }
 
 // ------------------------------------------------------------------------------------------ embed

@@ -50,6 +50,23 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
     return (uint16_t)(b >> 16);
 }
 
+// Two fp32 values -> packed bf16 pair (round to nearest even), one gfx950 instruction; lo half = a.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Exact three-term bf16 split of two fp32 values: x = hi + mid + lo (24 = 8 + 8 + 8 mantissa bits; every
+// residual is exactly representable).  Outputs are packed pairs {x1 : x0}.  11 VALU instructions per pair —
+// the integer-emulated rounding it replaces made the split the longest phase of the batched GEMV prologue.
+__device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - bf16_lo(hi), r1 = x1 - bf16_hi(hi);
+    mid = cvt_pk_bf16(r0, r1);
+    lo = cvt_pk_bf16(r0 - bf16_lo(mid), r1 - bf16_hi(mid));
+}
+
 // DPP row rotate inside each 16-lane row: every lane reads the lane `n` to its right (cyclic).
 template <int N>
 __device__ __forceinline__ float dpp_row_ror(float v) {
