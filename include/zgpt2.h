@@ -232,6 +232,20 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
  * Intervals are event-to-event, so each includes the boundary to the next kernel. */
 int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, size_t n_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tokenizer — src/bpe.zig (host side).  Encoder.init takes the two JSON objects of
+ * models/<size>/encoder.json (token string -> id) and byte_encoder.json (unicode char -> byte,
+ * download_weights.py:69-90) as parallel arrays of NUL-terminated UTF-8 keys and their values.
+ * encode / decode keep bpe.zig:60-118's behaviour, including its deviations from GPT-2 BPE (greedy longest
+ * prefix instead of merges, POSIX character classes, runs of spaces become their own word).  A word longer
+ * than the reference's 20-byte buffer (bpe.zig:73) returns ZG_ERR_SHAPE; n_out receives the count. */
+typedef struct zg_bpe zg_bpe;
+int zg_bpe_create(zg_bpe** out, const char* const* tokens, const size_t* token_ids, size_t n_tokens,
+                  const char* const* unicode_chars, const unsigned char* bytes, size_t n_bytes);
+int zg_bpe_destroy(zg_bpe* e);
+int zg_bpe_encode(zg_bpe* e, const char* text, size_t text_len, size_t* out, size_t out_cap, size_t* n_out);
+int zg_bpe_decode(zg_bpe* e, const size_t* ids, size_t n_ids, char* out, size_t out_cap, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,10 @@ SIGNATURES = {
     "zg_gpt_generate_fetch": (C.c_int, [vp, sz, vp, sz]),
     "zg_gpt_time_kernel": (C.c_int, [vp, C.c_int, C.c_int, f32p, szp]),
     "zg_gpt_profile_step": (C.c_int, [vp, sz, C.c_int, f32p, sz]),
+    "zg_bpe_create": (C.c_int, [C.POINTER(vp), vp, vp, sz, vp, vp, sz]),
+    "zg_bpe_destroy": (C.c_int, [vp]),
+    "zg_bpe_encode": (C.c_int, [vp, C.c_char_p, sz, vp, sz, szp]),
+    "zg_bpe_decode": (C.c_int, [vp, vp, sz, vp, sz, szp]),
 }
 
 # flags / slots of include/zgpt2.h
