@@ -6,14 +6,14 @@
 // accumulation).  To stay inside the same tolerance the GEMM A operand here is the fp32 activation split
 // into three bf16 terms, x = hi + mid + lo EXACTLY (24 = 8 + 8 + 8 mantissa bits; a two-term split leaves
 // 2^-18 |x| behind, which showed up as 2e-5 of the logit scale — outside the parity bar for logits that
-// happen to lie near zero), laid out [M][3K] = [hi | mid | lo]; the weight row is simply walked three
-// times (k index modulo K), so C = (hi + mid + lo) W^T accumulates in one fp32 MFMA chain.  Attention runs on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): no rounding of q, k,
+// happen to lie near zero), laid out [M][3K] = [hi | mid | lo]; every staged weight tile is multiplied with
+// the three planes, so C = (hi + mid + lo) W^T accumulates in one fp32 MFMA chain.  Attention runs on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): no rounding of q, k,
 // v or the probabilities at all.
 //
 // Kernels
 //   embed_prefill      x[m] = wte[token[m]] + wpe[t]                         (src/main.zig:179-183)
 //   ln_split           a = split(LayerNorm(x))                               (src/ops.zig:82-104)
-//   prefill_gemm       128 x 128 x 64 tile, LDS-DMA two-stage ring (see gemm_mfma.hip), epilogues:
+//   prefill_gemm       128 x 128 x 64 tile, weight tile shared by the three planes, LDS-DMA double buffer, epilogues:
 //                        F32 store | fp32 residual add | GELU + split        (ops.zig:21-46, main.zig:136-145, :79-80)
 //   kv_scatter         K / V columns of the qkv rows -> head-major caches    (src/ops.zig:152-158)
 //   attn_prefill       causal softmax(q k^T / 8) v, flash style, transposed so that every per-query
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------ GEMM
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;
-constexpr int kStageBytes = 2 * kTileBytes;
-constexpr int kStages = 4;                       // LDS ring depth: three K-steps of DMA in flight under the MFMAs
+constexpr int kStageBytes = (1 + kSplit) * kTileBytes;  // one weight tile + the three activation planes: 64 KiB
+constexpr int kStages = 2;
 constexpr int kLdsBytes = kStages * kStageBytes;  // 128 KiB; reused as the fp32 store staging area
 
 // rows beyond `rows` are clamped to the last valid row (loaded, never stored)
@@ -159,43 +159,43 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // every split plane of A walks the weight rows again: kSplit * K / 64 steps; slice sp takes [t0, nt)
-    const int nk = K / BK, nt_all = kSplit * nk;
-    const int t0 = (int)((long)nt_all * sp / n_sp), nt = (int)((long)nt_all * (sp + 1) / n_sp);
-    // Ring of kStages slots, one raw s_barrier per K-step and counted vmcnt (8 LDS-DMA loads per wave per
-    // stage): at the top of step t the stages t .. t + kStages - 2 are in flight; waiting until at most
-    // 8 (kStages - 2) loads remain means this wave's pieces of stage t landed, the barrier makes that true
-    // for every wave and also says slot (t - 1) % kStages is no longer read, so it is refilled right away.
+    // A K-step stages ONE 128 x 64 weight tile and the matching tile of each of the three activation planes;
+    // the weight fragments are read from LDS once and multiplied with all three planes (the first version
+    // walked the weight rows once per plane: 2 tiles per 16 MFMAs, and was bound by LDS-DMA at ~7 TB/s; this
+    // is 4 tiles per 48 MFMAs).  Two 64-KiB slots: the DMA of step t + 1 runs under the MFMAs of step t.
+    // Split-K slice sp takes the K-steps [t0, nt).
+    const int nk = K / BK;
+    const int t0 = (int)((long)nk * sp / n_sp), nt = (int)((long)nk * (sp + 1) / n_sp);
     auto issue = [&](int t) {
-        char* slot = lds + ((t - t0) % kStages) * kStageBytes;
-        stage_tile(A, kSplit * K, m0, M, t * BK, slot, wave, lane);
-        stage_tile(B, K, n0, N, (t % nk) * BK, slot + kTileBytes, wave, lane);
-    };
+        char* slot = lds + ((t - t0) & 1) * kStageBytes;
+        stage_tile(B, K, n0, N, t * BK, slot, wave, lane);
 #pragma unroll
-    for (int i = 0; i < kStages - 1; ++i)
-        if (t0 + i < nt) issue(t0 + i);
+        for (int p = 0; p < kSplit; ++p) stage_tile(A, kSplit * K, m0, M, p * K + t * BK, slot + (1 + p) * kTileBytes, wave, lane);
+    };
+    if (t0 < nt) issue(t0);
 
     const int frow = lane & 31, fk = lane >> 5;
     for (int t = t0; t < nt; ++t) {
-        const int ahead = nt - 1 - t;  // stages after t that were already issued (capped below)
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x4f70);       // vmcnt(16)
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
-        else __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        if (t + kStages - 1 < nt) issue(t + kStages - 1);
-        const char* cur = lds + ((t - t0) % kStages) * kStageBytes;
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of stage t landed
+        __builtin_amdgcn_s_barrier();        // everyone's did, and nobody still reads the other slot
+        if (t + 1 < nt) issue(t + 1);
+        const char* cur = lds + ((t - t0) & 1) * kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[2], b[2];
+            bf16x8 b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = read_frag(cur, wm * 64 + i * 32 + frow, kk * 2 + fk);
+            for (int j = 0; j < 2; ++j) b[j] = read_frag(cur, wn * 64 + j * 32 + frow, kk * 2 + fk);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = read_frag(cur + kTileBytes, wn * 64 + j * 32 + frow, kk * 2 + fk);
+            for (int p = kSplit - 1; p >= 0; --p) {  // smallest plane first
+                bf16x8 a[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) a[i] = read_frag(cur + (1 + p) * kTileBytes, wm * 64 + i * 32 + frow, kk * 2 + fk);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
     __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
@@ -272,10 +272,10 @@ int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, v
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
     // Few output tiles (N = n_embed, or a short prompt): slice K so that about one workgroup per CU exists
-    // (the 128-KiB ring allows one), at least 6 K-steps per slice, partial sums through the workspace.
-    const int nt = kSplit * K / BK;
+    // (the 128-KiB ring allows one), at least 3 K-steps per slice, partial sums through the workspace.
+    const int nt = K / BK;
     int n_sp = 256 / tiles;
-    if (n_sp > nt / 6) n_sp = nt / 6;
+    if (n_sp > nt / 3) n_sp = nt / 3;
     if (n_sp < 1) n_sp = 1;
     while (n_sp > 1 && (size_t)n_sp * M * N > ws_floats) --n_sp;
     static const int force = getenv("ZGPT2_PF_SPLITK") ? atoi(getenv("ZGPT2_PF_SPLITK")) : 0;
