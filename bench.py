@@ -110,7 +110,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # ZGPT2_FORCE_DIST=1 runs the RCCL path (process group, weight broadcast, barriers, max-reduce) with a
+    # single rank: the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("ZGPT2_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -133,7 +136,7 @@ def main():
         weights = synth.make_weights(cfg, seed=a.seed, bf16=not a.weights_f32)
         model.load_weights(weights)
     bcast_ms = None
-    if world > 1:
+    if use_dist:
         ptr, nbytes = model.weight_arena()
         arena = torch.as_tensor(_DevMem(ptr, nbytes), device=torch.device("cuda", local_rank))
         torch.cuda.synchronize()
