@@ -194,6 +194,10 @@ GPT_CASES = [
     ("tiny3", "tiny3", 2, 12, 1, 48, 1),
     ("nano-char", "nano-char", 3, 13, 4, 256, 1),
     ("124M", "124M", 0, 14, 2, 40, 53),
+    # long prompts: pin the whole-prompt prefill pass (zg_gpt_prefill inside generate) to the reference GPT
+    ("tiny-p24", "tiny", 4, 15, 24, 64, 1),
+    ("tiny3-p40", "tiny3", 5, 16, 40, 48, 1),
+    ("124M-p48", "124M", 0, 17, 48, 56, 53),
 ]
 
 
@@ -231,10 +235,13 @@ def make_gpt(ns, name, key, wseed, pseed, n_prompt, n_steps, stride):
 
 
 def main():
-    make_ops()
+    only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None  # e.g. "tiny-p24,124M-p48": just these GPT cases
+    if only is None:
+        make_ops()
     ns = load_reference_gpt_module()
     for case in GPT_CASES:
-        make_gpt(ns, *case)
+        if only is None or case[0] in only:
+            make_gpt(ns, *case)
 
 
 if __name__ == "__main__":

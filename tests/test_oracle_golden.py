@@ -85,7 +85,7 @@ def test_softmax(ops):  # src/tests.zig:362-388 (row by row)
     assert_ref_close(ops["softmax_outputs"], y, "softmax")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny3", "nano-char", "124M"])
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "nano-char", "124M", "tiny-p24", "tiny3-p40", "124M-p48"])
 def test_gpt_greedy_matches_reference_gpt(name):
     """Full model: oracle's generate loop (src/main.zig:322-342, greedy) vs the reference GPT."""
     cfg, g = load_gpt(name)

@@ -64,7 +64,24 @@ def test_prefill_batched_rows_are_independent(zg, kv_f16):
     m.close()
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny3", "nano-char", "124M"])
+@pytest.mark.parametrize("name", ["tiny-p24", "tiny3-p40", "124M-p48"])
+def test_prefill_then_teacher_forced_logits_match_reference_gpt(zg, name):
+    """Golden vectors of the reference's PyTorch GPT with long prompts (tests/golden/make_golden.py): the
+    prompt goes through zg_gpt_prefill in one pass, every later position through GPT.forward with the
+    reference's fed tokens; each step's logits must match the reference GPT's."""
+    cfg, g = load_gpt(name)
+    m, _ = make(cfg, int(g["weight_seed"]))
+    n_prompt, n_steps = len(g["prompt"]), len(g["out_tokens"])
+    m.prefill([g["prompt"]], compute_logits=False)
+    worst = 0.0
+    for s in range(n_prompt, n_steps):
+        lg = m.forward(s + 1, [g["fed"][s]])
+        worst = max(worst, assert_model_close(g["logits"][s - n_prompt], lg[0, g["logit_cols"]], f"{name} step {s}"))
+    print(f"{name}: worst normalised rel err vs reference GPT after prefill {worst:.2e}")
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "nano-char", "124M", "tiny-p24", "tiny3-p40", "124M-p48"])
 def test_generate_with_and_without_prefill_match_reference_gpt(zg, name):
     cfg, g = load_gpt(name)
     n_steps, n_prompt = len(g["out_tokens"]), len(g["prompt"])
