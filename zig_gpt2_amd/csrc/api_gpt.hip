@@ -432,6 +432,8 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     (void)hipMemset(g->arena + g->weight_region_bytes, 0, g->arena_bytes - g->weight_region_bytes);
     {
         GemvArgs a = base_gemv(g, g->wte, nullptr, c.vocab_size, c.n_embed, 0);
+        a.prologue = PRO_LAYERNORM;
+        a.epilogue = EPI_ARGMAX;  // the plan depends on the epilogue (workgroup width)
         g->lm_grid = gemv_plan(a, g->wt);
     }
     if (g->lm_grid > 4096) {

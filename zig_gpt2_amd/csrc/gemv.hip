@@ -319,10 +319,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     const int lr = lane % LPR, rsub = lane / LPR;
     const int nch = K >> 3, nq = K >> 2;
     const WT* W = reinterpret_cast<const WT*>(Wv);
+    // M == 1: waves are independent (wave-private prologue), so the workgroup may be 1..4 waves: matrices with
+    // few rows are launched as one-wave workgroups that the dispatcher spreads over all CUs
+    const int wpw = PERWAVE ? (int)(blockDim.x >> 6) : 4;
     float* xs = PERWAVE ? smem + (size_t)wave * K : smem;          // [MT][K] (per wave when M == 1)
-    float* red = smem + (size_t)(PERWAVE ? 4 : MT) * K;             // cross-wave scratch
+    float* red = smem + (size_t)(PERWAVE ? wpw : MT) * K;           // cross-wave scratch
 
-    const int gw = blockIdx.x * 4 + wave;
+    const int gw = blockIdx.x * wpw + wave;
     const int row_begin = gw * rows_per_wave;
     const int row_end = min(row_begin + rows_per_wave, N);
 
@@ -944,7 +947,8 @@ int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
 
 template <typename WT, int MT, int LPR, int CPL, bool ARGMAX>
 int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
-    const size_t lds = ((size_t)(MT == 1 ? 4 : MT) * a.K + 4 * MT * 2 + 64) * sizeof(float);
+    const int wpw = (MT == 1 && a.waves_per_wg >= 1 && a.waves_per_wg <= 4) ? a.waves_per_wg : 4;
+    const size_t lds = ((size_t)(MT == 1 ? wpw : MT) * a.K + 4 * MT * 2 + 64) * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised = false;  // opt in once per instantiation to >64 KiB dynamic LDS
         if (!raised) {
@@ -954,7 +958,7 @@ int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
         }
     }
     ZG_REQUIRE(lds <= 160 * 1024, ZG_ERR_UNSUPPORTED, "gemv: M=%d x K=%d does not fit LDS", a.M, a.K);
-    hipLaunchKernelGGL((gemv_kernel<WT, MT, LPR, CPL, ARGMAX>), dim3(grid), dim3(256), lds, s, a.W, a.x, a.N, a.K,
+    hipLaunchKernelGGL((gemv_kernel<WT, MT, LPR, CPL, ARGMAX>), dim3(grid), dim3(64 * wpw), lds, s, a.W, a.x, a.N, a.K,
                        a.M, a.rows_per_wave, a.prologue, a.epilogue, a.ln_g, a.ln_b, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -1042,7 +1046,12 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     }
     a.rows_per_wave = rpw;
     const int waves = (a.N + rpw - 1) / rpw;
-    return (waves + 3) / 4;
+    // M == 1 without the argmax tail: one-wave workgroups while the matrix has at most ~4 waves per CU
+    static const int wpw_env = getenv("ZGPT2_WPW") ? atoi(getenv("ZGPT2_WPW")) : 0;
+    int wpw = 4;
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 1024 ? 1 : 4);
+    a.waves_per_wg = wpw;
+    return (waves + wpw - 1) / wpw;
 }
 
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {

@@ -27,6 +27,7 @@ struct GemvArgs {
     const float* bias;  // [N] or nullptr
     int N, K, M;
     int rows_per_wave;
+    int waves_per_wg;  // filled by gemv_plan (M == 1 kernels may run as 1..4-wave workgroups)
     int prologue, epilogue;
     // PRO_NONE / PRO_LAYERNORM input
     const float* x;  // [M][x_stride]
