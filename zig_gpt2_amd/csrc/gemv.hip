@@ -322,7 +322,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     // M == 1: waves are independent (wave-private prologue), so the workgroup may be 1..4 waves: matrices with
     // few rows are launched as one-wave workgroups that the dispatcher spreads over all CUs
     const int wpw = PERWAVE ? (int)(blockDim.x >> 6) : 4;
-    float* xs = PERWAVE ? smem + (size_t)wave * K : smem;          // [MT][K] (per wave when M == 1)
+    // A wide un-normalised input (mlp c_proj: K = 4 E) is as many bytes per wave as the wave's weight rows, so the
+    // waves of a workgroup share ONE copy of it (a quarter of the fetch each, one barrier); everything else
+    // keeps wave-private strips and no barrier.
+    const bool shared_x = PERWAVE && wpw > 1 && prologue == PRO_NONE;
+    float* xs = (PERWAVE && !shared_x) ? smem + (size_t)wave * K : smem;  // [MT][K] (per wave when M == 1)
     float* red = smem + (size_t)(PERWAVE ? wpw : MT) * K;           // cross-wave scratch
 
     const int gw = blockIdx.x * wpw + wave;
@@ -366,6 +370,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
             const int t_hi = a.t_hi > 0 ? a.t_hi : T;
             const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
             for (int i = lane; i < nq; i += 64) xw4[i] = merge_attn4(a, 0, i * 4, nsplit);
+        } else if (shared_x) {
+            const int nthr = 64 * wpw;
+            f32x4 v[8];  // K <= 8192: all loads in flight at once
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const f32x4*>(xin)[min(tid + nthr * j, nq - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (tid + nthr * j < nq) xw4[tid + nthr * j] = v[j];
+            __syncthreads();
         } else {
             for (int i = lane; i < nq; i += 64) xw4[i] = reinterpret_cast<const f32x4*>(xin)[i];
         }
@@ -1050,6 +1063,8 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     static const int wpw_env = getenv("ZGPT2_WPW") ? atoi(getenv("ZGPT2_WPW")) : 0;
     int wpw = 4;
     if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 1024 ? 1 : 4);
+    static const int share_k = getenv("ZGPT2_SHARE_K") ? atoi(getenv("ZGPT2_SHARE_K")) : 2048;
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= share_k && a.K <= 8192) wpw = 4;
     a.waves_per_wg = wpw;
     return (waves + wpw - 1) / wpw;
 }
