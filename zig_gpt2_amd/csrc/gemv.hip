@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     // A wide un-normalised input (mlp c_proj: K = 4 E) is as many bytes per wave as the wave's weight rows, so the
     // waves of a workgroup share ONE copy of it (a quarter of the fetch each, one barrier); everything else
     // keeps wave-private strips and no barrier.
-    const bool shared_x = PERWAVE && wpw > 1 && prologue == PRO_NONE;
+    const bool shared_x = PERWAVE && wpw > 1 && (prologue == PRO_NONE || prologue == PRO_ATTN_MERGE);
     float* xs = (PERWAVE && !shared_x) ? smem + (size_t)wave * K : smem;  // [MT][K] (per wave when M == 1)
     float* red = smem + (size_t)(PERWAVE ? wpw : MT) * K;           // cross-wave scratch
 
@@ -366,6 +366,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
             const float mean = t1 / (float)K;
             const float rstd = 1.0f / sqrtf(t2 / (float)K - mean * mean + a.eps);
             for (int k = lane; k < K; k += 64) xs[k] = fmaf((xs[k] - mean) * rstd, ln_g[k], ln_b[k]);
+        } else if (prologue == PRO_ATTN_MERGE && shared_x) {
+            // the head merge is spread over the whole workgroup: one float4 of the merged vector per thread
+            const int t_hi = a.t_hi > 0 ? a.t_hi : T;
+            const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
+            for (int i = tid; i < nq; i += 64 * wpw) xw4[i] = merge_attn4(a, 0, i * 4, nsplit);
+            __syncthreads();
         } else if (prologue == PRO_ATTN_MERGE) {
             const int t_hi = a.t_hi > 0 ? a.t_hi : T;
             const int nsplit = (t_hi + kAttnChunk - 1) / kAttnChunk;
@@ -1065,6 +1071,8 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 1024 ? 1 : 4);
     static const int share_k = getenv("ZGPT2_SHARE_K") ? atoi(getenv("ZGPT2_SHARE_K")) : 2048;
     if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= share_k && a.K <= 8192) wpw = 4;
+    static const int share_merge = getenv("ZGPT2_SHARE_MERGE") ? atoi(getenv("ZGPT2_SHARE_MERGE")) : 4;
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_ATTN_MERGE && share_merge > 1) wpw = share_merge;
     a.waves_per_wg = wpw;
     return (waves + wpw - 1) / wpw;
 }
