@@ -1070,7 +1070,9 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     int wpw = 4;
     if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 1024 ? 1 : 4);
     static const int share_k = getenv("ZGPT2_SHARE_K") ? atoi(getenv("ZGPT2_SHARE_K")) : 2048;
-    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= share_k && a.K <= 8192) wpw = 4;
+    static const int share_wpw = getenv("ZGPT2_SHARE_WPW") ? atoi(getenv("ZGPT2_SHARE_WPW")) : 0;
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= share_k && a.K <= 8192)
+        wpw = share_wpw > 0 ? share_wpw : 2;  // measured in situ: 2 >= 4 at K = 3072 (124M) and K = 6400 (XL)
     static const int share_merge = getenv("ZGPT2_SHARE_MERGE") ? atoi(getenv("ZGPT2_SHARE_MERGE")) : 4;
     if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_ATTN_MERGE && share_merge > 1) wpw = share_merge;
     a.waves_per_wg = wpw;
