@@ -850,7 +850,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     const int pos = T - 1;
     const size_t plane = (size_t)kMfmaRows * S;
     const char* arow = planes + (size_t)(lane & 7) * S + bq * 16;  // A fragment: batch row (lane & 15) & 7
-    float* partial = red + 64;                                     // [2 buffers][NW waves][64 lanes][4]
+    // [2 buffers][NW waves][64 lanes][4].  When the planes alone nearly fill the LDS (K = 3072: 148 KiB) and the
+    // workgroup owns a single tile, the partial tiles reuse the plane area once every wave has read its fragments.
+    const bool alias_partial = a.waves_per_wg < 0;
+    float* partial = alias_partial ? reinterpret_cast<float*>(planes) : red + 64;
     int buf = 0;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         mf_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -870,6 +873,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
         }
         if (tile == tile_begin) ZG_STAMP(4);
         if (tile + 1 < tile_end) load_tile(tile + 1);  // next tile's weights fly under the epilogue
+        if (alias_partial) __syncthreads();  // all A fragments consumed: the plane area becomes the exchange buffer
         *reinterpret_cast<mf_f32x4*>(partial + ((buf * NW + wave) * 64 + lane) * 4) = acc;
         __syncthreads();
         if (tile == tile_begin) ZG_STAMP(5);
@@ -929,13 +933,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 
 inline int gemv_mfma_waves(const GemvArgs& a) { return a.epilogue == EPI_ARGMAX ? 4 : 16; }
 
-inline size_t gemv_mfma_lds(int K, int nw) {
-    return (size_t)3 * kMfmaRows * (2 * K + 16) + (64 + 2 * nw * 64 * 4) * sizeof(float);
+inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false) {
+    const size_t planes = (size_t)3 * kMfmaRows * (2 * K + 16);
+    return planes + 64 * sizeof(float) + (alias_partial ? 0 : (size_t)2 * nw * 64 * 4 * sizeof(float));
+}
+
+// single-tile workgroups may let the partial tiles alias the planes (see the kernel)
+inline bool gemv_mfma_alias(const GemvArgs& a) {
+    return a.epilogue != EPI_ARGMAX && a.rows_per_wave == 1 && gemv_mfma_lds(a.K, 16) > 160 * 1024;
 }
 
 template <int KS, int NW, bool ARGMAX>
 int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
-    const size_t lds = gemv_mfma_lds(a.K, NW);
+    const bool alias = gemv_mfma_alias(a);
+    const size_t lds = gemv_mfma_lds(a.K, NW, alias);
+    GemvArgs b = a;
+    b.waves_per_wg = alias ? -1 : NW;  // < 0: partial tiles alias the planes
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX>),
@@ -944,7 +957,7 @@ int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX>), dim3(grid), dim3(NW * 64), lds, s,
                        reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K, a.M, a.rows_per_wave, a.prologue,
-                       a.epilogue, a.ln_g, a.ln_b, a);
+                       a.epilogue, a.ln_g, a.ln_b, b);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -1042,7 +1055,10 @@ bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
     if (off || weight_type != WT_BF16 || a.M < 2 || a.M > kMfmaRows) return false;
     if (a.K % 32 != 0 || a.K / 32 < 4 || a.K / 32 > 96) return false;
     if (a.prologue == PRO_LAYERNORM && a.K > 2048) return false;
-    return gemv_mfma_lds(a.K, gemv_mfma_waves(a)) <= 160 * 1024;
+    if (gemv_mfma_lds(a.K, gemv_mfma_waves(a)) <= 160 * 1024) return true;
+    // wide K: only as single-tile workgroups whose partial tiles alias the planes
+    static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
+    return a.epilogue != EPI_ARGMAX && (a.N + 15) / 16 <= wgs && gemv_mfma_lds(a.K, 16, true) <= 160 * 1024;
 }
 
 int gemv_plan(GemvArgs& a, int weight_type) {
