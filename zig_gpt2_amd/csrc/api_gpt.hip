@@ -436,6 +436,16 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         a.epilogue = EPI_ARGMAX;  // the plan depends on the epilogue (workgroup width)
         g->lm_grid = gemv_plan(a, g->wt);
     }
+    {   // the widest input of a Block (mlp c_proj: 4 E floats per sequence) must fit the batched kernels' LDS
+        GemvArgs a = base_gemv(g, g->layers[0].mlp_proj_w, nullptr, c.n_embed, 4 * c.n_embed, 0);
+        if (!gemv_supported(a, g->wt)) {
+            (void)hipFree(g->arena);
+            delete g;
+            set_error("batch %zu with n_embed %zu: %zu input rows of 4*n_embed floats do not fit the LDS (use a smaller batch)",
+                      batch, c.n_embed, batch);
+            return ZG_ERR_UNSUPPORTED;
+        }
+    }
     if (g->lm_grid > 4096) {
         (void)hipFree(g->arena);
         delete g;

@@ -378,12 +378,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
             for (int i = lane; i < nq; i += 64) xw4[i] = merge_attn4(a, 0, i * 4, nsplit);
         } else if (shared_x) {
             const int nthr = 64 * wpw;
-            f32x4 v[8];  // K <= 8192: all loads in flight at once
+            for (int base = 0; base < nq; base += 8 * nthr) {  // 8 loads per thread in flight at once
+                f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const f32x4*>(xin)[min(tid + nthr * j, nq - 1)];
+                for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const f32x4*>(xin)[min(base + tid + nthr * j, nq - 1)];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (tid + nthr * j < nq) xw4[tid + nthr * j] = v[j];
+                for (int j = 0; j < 8; ++j)
+                    if (base + tid + nthr * j < nq) xw4[base + tid + nthr * j] = v[j];
+            }
             __syncthreads();
         } else {
             for (int i = lane; i < nq; i += 64) xw4[i] = reinterpret_cast<const f32x4*>(xin)[i];
@@ -1059,6 +1061,13 @@ bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
     // wide K: only as single-tile workgroups whose partial tiles alias the planes
     static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
     return a.epilogue != EPI_ARGMAX && (a.N + 15) / 16 <= wgs && gemv_mfma_lds(a.K, 16, true) <= 160 * 1024;
+}
+
+// Can a Linear with this M and K run at all?  (The batched kernels keep all M input rows in LDS.)
+bool gemv_supported(const GemvArgs& a, int weight_type) {
+    if (a.M <= 1 || gemv_use_mfma(a, weight_type)) return true;
+    const int mt = a.M <= 2 ? 2 : (a.M <= 4 ? 4 : 8);
+    return ((size_t)mt * a.K + 4 * mt * 2 + 64) * sizeof(float) <= 160 * 1024;
 }
 
 int gemv_plan(GemvArgs& a, int weight_type) {

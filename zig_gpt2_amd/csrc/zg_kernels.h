@@ -60,6 +60,8 @@ struct GemvArgs {
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
 };
 
+// Whether launch_gemv can run this M x K at all (batched kernels keep the M input rows in LDS).
+bool gemv_supported(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s);

@@ -104,6 +104,7 @@ CONFIGS = {
     "nano-char": GPTConfig(65, 256, 6, 6, 384),
     "tiny": GPTConfig(257, 64, 2, 2, 128),  # test-only
     "tiny3": GPTConfig(131, 48, 3, 3, 192),  # test-only, odd sizes
+    "xl-slice": GPTConfig(1031, 96, 2, 25, 1600),  # test-only: GPT-2 XL's layer shapes (E = 1600, 25 heads), 2 layers
 }
 
 BLOCK_TENSORS = [
