@@ -227,3 +227,18 @@ def test_xl_layer_shapes_match_oracle(zg, batch):
 
         with pytest.raises(_lib.ZgError):
             zgpt.GPT(cfg, batch=8)
+
+
+def test_nano_char_batched_matches_oracle(zg):
+    """E = 384 shapes (K = 384 / 1536) through the lock-step batched kernels."""
+    cfg = synth.CONFIGS["nano-char"]
+    m, w = make(cfg, 91, batch=3)
+    prompts = [synth.rand_tokens(910 + b, 2 + 3 * b, cfg.vocab_size) for b in range(3)]
+    n_steps = 96
+    ids = m.generate(prompts, n_steps)
+    for b in range(3):
+        ids_ref, lg = oracle.GPT(cfg, w).generate_greedy(prompts[b], n_steps, want_logits=True)
+        top = np.sort(lg, axis=1)
+        n = len(prompts[b])
+        assert_greedy_ids_match(ids_ref[n:], ids[b, n:], top[:, -1], top[:, -2], f"nano-char row {b}")
+    m.close()
