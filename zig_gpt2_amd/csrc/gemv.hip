@@ -1090,10 +1090,10 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     }
     a.rows_per_wave = rpw;
     const int waves = (a.N + rpw - 1) / rpw;
-    // M == 1 without the argmax tail: one-wave workgroups while the matrix has at most ~4 waves per CU
+    // M == 1 without the argmax tail: one-wave workgroups while the matrix has at most ~8 waves per CU
     static const int wpw_env = getenv("ZGPT2_WPW") ? atoi(getenv("ZGPT2_WPW")) : 0;
     int wpw = 4;
-    if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 1024 ? 1 : 4);
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 2048 ? 1 : 4);
     static const int share_k = getenv("ZGPT2_SHARE_K") ? atoi(getenv("ZGPT2_SHARE_K")) : 2048;
     static const int share_wpw = getenv("ZGPT2_SHARE_WPW") ? atoi(getenv("ZGPT2_SHARE_WPW")) : 0;
     if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= share_k && a.K <= 8192)
