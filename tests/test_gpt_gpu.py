@@ -242,3 +242,17 @@ def test_nano_char_batched_matches_oracle(zg):
         n = len(prompts[b])
         assert_greedy_ids_match(ids_ref[n:], ids[b, n:], top[:, -1], top[:, -2], f"nano-char row {b}")
     m.close()
+
+
+def test_xl_layer_shapes_fp32_weights_match_oracle(zg):
+    """The same wide shapes with ZG_GPT_WEIGHTS_F32 (fp32 weight storage, not bf16-representable values)."""
+    cfg = synth.CONFIGS["xl-slice"]
+    w = synth.make_weights(cfg, seed=82, bf16=False)
+    m = zgpt.GPT(cfg, weights_f32=True)
+    m.load_weights(w)
+    prompt = synth.rand_tokens(821, 3, cfg.vocab_size)
+    ids = m.generate([prompt], 32)[0]
+    ids_ref, lg = oracle.GPT(cfg, w).generate_greedy(prompt, 32, want_logits=True)
+    top = np.sort(lg, axis=1)
+    assert_greedy_ids_match(ids_ref[3:], ids[3:], top[:, -1], top[:, -2], "xl-slice fp32 weights")
+    m.close()
