@@ -98,7 +98,8 @@ def test_softmax_golden(zg, g):  # src/tests.zig:362-388: row by row
 # ------------------------------------------------------------------ seeded sweeps vs the oracle
 @pytest.mark.parametrize("m,k,n", [(1, 768, 2304), (1, 3072, 768), (3, 768, 3072), (8, 768, 768), (9, 384, 1152),
                                    (17, 128, 65), (1, 1600, 4800), (2, 6400, 1600), (5, 1536, 384), (1, 768, 50257),
-                                   (4, 100, 37), (1, 8, 1), (2, 64, 3)])
+                                   (4, 100, 37), (1, 8, 1), (2, 64, 3), (1, 6400, 1600), (1, 8192, 264), (1, 2048, 72),
+                                   (1, 4104, 40), (4, 6400, 64)])
 def test_linear_sweep(zg, m, k, n):
     w = synth.fill_normal(100 + n, n * k, 0, 0.05).reshape(n, k)
     b = synth.fill_normal(200 + n, n, 0, 0.05)
