@@ -13,7 +13,8 @@
 // Kernels
 //   embed_prefill      x[m] = wte[token[m]] + wpe[t]                         (src/main.zig:179-183)
 //   ln_split           a = split(LayerNorm(x))                               (src/ops.zig:82-104)
-//   prefill_gemm       128 x 128 x 64 tile, weight tile shared by the three planes, LDS-DMA double buffer, epilogues:
+//   prefill_gemm       128 x 128 (or 128 x 256) x 64 tile, weight tile shared by the three planes, LDS-DMA double
+//                      buffer, epilogues:
 //                        F32 store | fp32 residual add | GELU + split        (ops.zig:21-46, main.zig:136-145, :79-80)
 //   kv_scatter         K / V columns of the qkv rows -> head-major caches    (src/ops.zig:152-158)
 //   attn_prefill       causal softmax(q k^T / 8) v, flash style, transposed so that every per-query
@@ -105,16 +106,18 @@ __global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------ GEMM
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;
-constexpr int kStageBytes = (1 + kSplit) * kTileBytes;  // one weight tile + the three activation planes: 64 KiB
 constexpr int kStages = 2;
-constexpr int kLdsBytes = kStages * kStageBytes;  // 128 KiB; reused as the fp32 store staging area
+// stage = weight tile (128 NS rows) + the three activation planes: 64 KiB (NS = 1) or 80 KiB (NS = 2)
+constexpr int stage_bytes(int ns) { return (ns + kSplit) * kTileBytes; }
+constexpr int lds_bytes(int ns) { return kStages * stage_bytes(ns); }  // 128 / 160 KiB; reused as store staging
 
 // rows beyond `rows` are clamped to the last valid row (loaded, never stored)
+template <int PPW = 4>  // 1-KiB pieces (8 rows x 128 B) per wave: 4 for a 128-row tile, 8 for 256 rows
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int rows, int k0, char* lds_tile,
                                            int wave, int lane) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave * 4 + q;
+    for (int q = 0; q < PPW; ++q) {
+        const int piece = wave * PPW + q;
         const int row = piece * 8 + (lane >> 3);
         const int pos = lane & 7;
         const int chunk = pos ^ ((row >> 1) & 7);
@@ -137,7 +140,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 // A: [M][3K] bf16 (hi | mid | lo), B: [N][K] bf16, bias [N].  C: fp32 [M][ldc] (PF_F32, PF_RESID) or bf16
 // [M][3N] split planes (PF_GELU_SPLIT).  N % 64 == 0, K % 64 == 0, any M.
-template <int EPI>
+template <int EPI, int NS>  // NS 64-column strips per wave: the tile is 128 x (128 NS)
 __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                               const float* __restrict__ bias, void* __restrict__ C, int M,
                                                               int N, int K, int ldc, int tiles_n, int n_tiles) {
@@ -149,13 +152,14 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
     const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    constexpr int BNT = BN * NS, NJ = 2 * NS, kStageB = stage_bytes(NS), kBBytes = NS * kTileBytes;
+    const int m0 = tm * BM, n0 = tn * BNT;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -167,10 +171,10 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
     const int nk = K / BK;
     const int t0 = (int)((long)nk * sp / n_sp), nt = (int)((long)nk * (sp + 1) / n_sp);
     auto issue = [&](int t) {
-        char* slot = lds + ((t - t0) & 1) * kStageBytes;
-        stage_tile(B, K, n0, N, t * BK, slot, wave, lane);
+        char* slot = lds + ((t - t0) & 1) * kStageB;
+        stage_tile<4 * NS>(B, K, n0, N, t * BK, slot, wave, lane);
 #pragma unroll
-        for (int p = 0; p < kSplit; ++p) stage_tile(A, kSplit * K, m0, M, p * K + t * BK, slot + (1 + p) * kTileBytes, wave, lane);
+        for (int p = 0; p < kSplit; ++p) stage_tile(A, kSplit * K, m0, M, p * K + t * BK, slot + kBBytes + p * kTileBytes, wave, lane);
     };
     if (t0 < nt) issue(t0);
 
@@ -179,60 +183,63 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of stage t landed
         __builtin_amdgcn_s_barrier();        // everyone's did, and nobody still reads the other slot
         if (t + 1 < nt) issue(t + 1);
-        const char* cur = lds + ((t - t0) & 1) * kStageBytes;
+        const char* cur = lds + ((t - t0) & 1) * kStageB;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 b[2];
+            bf16x8 b[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = read_frag(cur, wn * 64 + j * 32 + frow, kk * 2 + fk);
+            for (int j = 0; j < NJ; ++j) b[j] = read_frag(cur, wn * 64 * NS + j * 32 + frow, kk * 2 + fk);
 #pragma unroll
             for (int p = kSplit - 1; p >= 0; --p) {  // smallest plane first
                 bf16x8 a[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = read_frag(cur + (1 + p) * kTileBytes, wm * 64 + i * 32 + frow, kk * 2 + fk);
+                for (int i = 0; i < 2; ++i) a[i] = read_frag(cur + kBBytes + p * kTileBytes, wm * 64 + i * 32 + frow, kk * 2 + fk);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
     }
     __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
 
-    // epilogue: the wave's 64 x 64 fp32 strip goes through LDS so that global accesses are 16-B row segments
-    const int nw = n0 + wn * 64;
-    if (nw >= N) return;  // N % 64 == 0: a strip is entirely inside or entirely outside
+    // epilogue: each 64 x 64 fp32 strip of the wave goes through LDS so that global accesses are 16-B row segments
     float* wtile = reinterpret_cast<float*>(lds + wave * (64 * 64 * 4));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j * 32 + frow;
-        const float bv = (EPI != PF_PARTIAL && bias) ? bias[nw + col] : 0.0f;
+    for (int st = 0; st < NS; ++st) {
+        const int nw = n0 + (wn * NS + st) * 64;
+        if (nw >= N) break;  // N % 64 == 0: a strip is entirely inside or entirely outside
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + frow;
+            const float bv = (EPI != PF_PARTIAL && bias) ? bias[nw + col] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                float v = acc[i][j][r] + bv;
-                if (EPI == PF_GELU_SPLIT) v = gelu_fast(v);
-                wtile[row * 64 + col] = v;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    float v = acc[i][st * 2 + j][r] + bv;
+                    if (EPI == PF_GELU_SPLIT) v = gelu_fast(v);
+                    wtile[row * 64 + col] = v;
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int c = it * 64 + lane;
+            const int row = c >> 4, cc = c & 15;
+            const int gm = m0 + wm * 64 + row;
+            if (gm >= M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(wtile + row * 64 + cc * 4);
+            if (EPI == PF_GELU_SPLIT) {
+                store_split4(reinterpret_cast<bf16_t*>(C) + (size_t)gm * kSplit * N + nw + cc * 4, N, v);
+            } else if (EPI == PF_PARTIAL) {  // C is the workspace [n_sp][M][N]
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ((size_t)sp * M + gm) * N + nw + cc * 4) = v;
+            } else {
+                float* dst = reinterpret_cast<float*>(C) + (size_t)gm * ldc + nw + cc * 4;
+                if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = v;
             }
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c >> 4, cc = c & 15;
-        const int gm = m0 + wm * 64 + row;
-        if (gm >= M) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(wtile + row * 64 + cc * 4);
-        if (EPI == PF_GELU_SPLIT) {
-            store_split4(reinterpret_cast<bf16_t*>(C) + (size_t)gm * kSplit * N + nw + cc * 4, N, v);
-        } else if (EPI == PF_PARTIAL) {  // C is the workspace [n_sp][M][N]
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ((size_t)sp * M + gm) * N + nw + cc * 4) = v;
-        } else {
-            float* dst = reinterpret_cast<float*>(C) + (size_t)gm * ldc + nw + cc * 4;
-            if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
-            *reinterpret_cast<f32x4*>(dst) = v;
         }
     }
 }
@@ -259,20 +266,20 @@ __global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __rest
     }
 }
 
-template <int EPI>
-int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                          float* ws, size_t ws_floats, hipStream_t s) {
+template <int EPI, int NS>
+int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                           float* ws, size_t ws_floats, hipStream_t s) {
     static bool raised = false;
     if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<PF_PARTIAL>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI, NS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(NS)));
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<PF_PARTIAL, NS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(NS)));
         raised = true;
     }
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN * NS - 1) / (BN * NS), tiles = tiles_m * tiles_n;
     // Few output tiles (N = n_embed, or a short prompt): slice K so that about one workgroup per CU exists
-    // (the 128-KiB ring allows one), at least 3 K-steps per slice, partial sums through the workspace.
+    // (the LDS ring allows one), at least 3 K-steps per slice, partial sums through the workspace.
     const int nt = K / BK;
     int n_sp = 256 / tiles;
     if (n_sp > nt / 3) n_sp = nt / 3;
@@ -281,10 +288,10 @@ int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, v
     static const int force = getenv("ZGPT2_PF_SPLITK") ? atoi(getenv("ZGPT2_PF_SPLITK")) : 0;
     if (force > 0) n_sp = force;
     if (n_sp <= 1 || !ws) {
-        hipLaunchKernelGGL((prefill_gemm_kernel<EPI>), dim3(tiles), dim3(256), kLdsBytes, s, A, B, bias, C, M, N, K, ldc,
-                           tiles_n, tiles);
+        hipLaunchKernelGGL((prefill_gemm_kernel<EPI, NS>), dim3(tiles), dim3(256), lds_bytes(NS), s, A, B, bias, C, M, N, K,
+                           ldc, tiles_n, tiles);
     } else {
-        hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL>), dim3(tiles, n_sp), dim3(256), kLdsBytes, s, A, B, bias,
+        hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL, NS>), dim3(tiles, n_sp), dim3(256), lds_bytes(NS), s, A, B, bias,
                            (void*)ws, M, N, K, ldc, tiles_n, tiles);
         const size_t n = (size_t)M * (N / 4);
         hipLaunchKernelGGL((prefill_reduce_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n_sp, bias, C,
@@ -292,6 +299,18 @@ int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, v
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
+}
+
+// 128 x 256 tiles (the staged weight tile is shared by the three planes, so widening N is the cheap direction:
+// 157 FLOP per staged byte against 96) once there are enough rows to fill the chip with them, else 128 x 128.
+template <int EPI>
+int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                          float* ws, size_t ws_floats, hipStream_t s) {
+    static const int wide_env = getenv("ZGPT2_PF_WIDE") ? atoi(getenv("ZGPT2_PF_WIDE")) : -1;
+    const int wide_tiles = ((M + BM - 1) / BM) * ((N + 2 * BN - 1) / (2 * BN));
+    const bool wide = wide_env >= 0 ? wide_env != 0 : (wide_tiles >= 256 && N >= 2 * BN);
+    if (wide) return launch_prefill_gemm_ns<EPI, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
+    return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
 }
 
 // ------------------------------------------------------------------------------------------ KV scatter
