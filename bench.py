@@ -269,7 +269,7 @@ def main():
             "tokens_counted": "generated tokens (context - prompt) per prompt",
         },
         "roofline": {
-            "kernel": ("gemv_kernel<bf16,M=1,LPR16,CPL6,ARGMAX>" if ppg == 1 else "gemv_mfma_kernel<KS=6,ARGMAX,SPLITK>") +
+            "kernel": ("gemv_kernel<bf16,M=1,LPR16,CPL6,ARGMAX>" if ppg == 1 else "gemv_mfma_kernel<KS=6,NW=4,ARGMAX>") +
                       " (ln_f + lm_head + argmax)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
