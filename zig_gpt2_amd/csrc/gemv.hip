@@ -4,7 +4,7 @@
 // is tiny (decode: M = number of lock-step sequences).  HBM-bandwidth bound: every weight byte is
 // read exactly once, 16 B per lane, K-contiguous rows ([out,in] layout of ops.Linear.weight), so
 // one row is read by a group of LPR lanes with fully coalesced 16-B loads and reduced with DPP
-// row rotations (no LDS, no barriers in the M == 1 path).
+// row rotations (M == 1: no barrier, except where a workgroup shares one copy of a wide input).
 //
 // Fused around the dot products (the reference does these as separate host loops / ops):
 //   prologue  PRO_LAYERNORM   LayerNorm.forward of the input row   (src/ops.zig:82-104)
@@ -292,7 +292,9 @@ __device__ __forceinline__ void ln_strip(const float* __restrict__ xin, const fl
     }
 }
 
-// One workgroup = 4 waves; each wave owns rows [gw * rows_per_wave, +rows_per_wave).
+// One workgroup = 1..4 waves (M == 1: gemv_plan picks one wave for narrow matrices so that the dispatcher spreads
+// them over all CUs, two / four where the waves share one input strip; M > 1: four); each wave owns rows
+// [gw * rows_per_wave, +rows_per_wave).
 // LPR lanes share one row (RPP = 64 / LPR rows per pass); CPL 16-B chunks per lane per row.
 //
 // Every kernel of a decode step except lm_head is bound by its chain of dependent memory round
