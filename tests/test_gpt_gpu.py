@@ -197,11 +197,12 @@ def test_sampler_matches_reference_sampling_rule(zg):
     m.close()
 
 
-@pytest.mark.parametrize("batch", [1, 4])
+@pytest.mark.parametrize("batch", [1, 4, 8])
 def test_xl_layer_shapes_match_oracle(zg, batch):
     """GPT-2 XL's layer shapes (E = 1600: 1600 -> 4800 / 1600 / 6400, 6400 -> 1600, 25 heads) in a 2-layer
     model the oracle finishes in seconds: the wide-K kernel instantiations (64 lanes per row, shared input
-    strips, the K = 6400 batched path) against independent reference-style generations, and the prefill
+    strips, the K = 6400 batched path — at batch 8 its rows do not fit the LDS and run as two groups of four)
+    against independent reference-style generations, and the prefill
     GEMMs with N not a multiple of the 128-column tile."""
     cfg = synth.CONFIGS["xl-slice"]
     m, w = make(cfg, 81, batch=batch)
@@ -222,11 +223,6 @@ def test_xl_layer_shapes_match_oracle(zg, batch):
         assert_model_close(lg_ref[0], lg[b], f"xl-slice prefill row {b}")
         assert_model_close(lg_ref[1], nxt[b], f"xl-slice decode after prefill row {b}")
     m.close()
-    if batch == 4:  # 8 rows of 6400 floats exceed the LDS of the batched kernels: refused when the handle is created
-        from zig_gpt2_amd import _lib
-
-        with pytest.raises(_lib.ZgError):
-            zgpt.GPT(cfg, batch=8)
 
 
 def test_nano_char_batched_matches_oracle(zg):

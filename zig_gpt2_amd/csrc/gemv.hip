@@ -1066,10 +1066,25 @@ bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
 }
 
 // Can a Linear with this M and K run at all?  (The batched kernels keep all M input rows in LDS.)
+namespace {
+inline size_t valu_lds(int mt, int K) { return ((size_t)mt * K + 4 * mt * 2 + 64) * sizeof(float); }
+inline int valu_mt(int M) { return M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8)); }
+// Rows of a plain (no prologue) Linear are independent: when M rows of K floats exceed the LDS the batch is
+// run as row groups that fit (the weights are streamed once per group).
+inline bool splittable(const GemvArgs& a) {
+    return a.prologue == PRO_NONE && (a.epilogue == EPI_STORE || a.epilogue == EPI_RESIDUAL || a.epilogue == EPI_GELU);
+}
+inline int row_group(const GemvArgs& a) {
+    int g = valu_mt(a.M);
+    while (g > 1 && valu_lds(g, a.K) > 160 * 1024) g >>= 1;
+    return g;
+}
+}  // namespace
+
 bool gemv_supported(const GemvArgs& a, int weight_type) {
     if (a.M <= 1 || gemv_use_mfma(a, weight_type)) return true;
-    const int mt = a.M <= 2 ? 2 : (a.M <= 4 ? 4 : 8);
-    return ((size_t)mt * a.K + 4 * mt * 2 + 64) * sizeof(float) <= 160 * 1024;
+    if (valu_lds(valu_mt(a.M), a.K) <= 160 * 1024) return true;
+    return splittable(a) && valu_lds(row_group(a), a.K) <= 160 * 1024;
 }
 
 int gemv_plan(GemvArgs& a, int weight_type) {
@@ -1108,6 +1123,20 @@ int gemv_plan(GemvArgs& a, int weight_type) {
 
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
     if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);
+    if (a.M > 1 && valu_lds(valu_mt(a.M), a.K) > 160 * 1024 && splittable(a)) {
+        const int g = row_group(a);
+        for (int m0 = 0; m0 < a.M; m0 += g) {
+            GemvArgs b = a;
+            b.M = a.M - m0 < g ? a.M - m0 : g;
+            b.x = a.x + (size_t)m0 * a.x_stride;
+            b.y = a.y + (size_t)m0 * a.y_stride;
+            if (a.resid) b.resid = a.resid + (size_t)m0 * a.resid_stride;
+            GemvArgs p = b;
+            const int gb = gemv_plan(p, weight_type);  // M == 1 groups are planned differently
+            ZG_TRY(weight_type == WT_BF16 ? launch_wt<bf16_t>(p, gb, s) : launch_wt<float>(p, gb, s));
+        }
+        return ZG_OK;
+    }
     return weight_type == WT_BF16 ? launch_wt<bf16_t>(a, grid, s) : launch_wt<float>(a, grid, s);
 }
 
