@@ -252,3 +252,37 @@ def test_xl_layer_shapes_fp32_weights_match_oracle(zg):
     top = np.sort(lg, axis=1)
     assert_greedy_ids_match(ids_ref[3:], ids[3:], top[:, -1], top[:, -2], "xl-slice fp32 weights")
     m.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 8])
+def test_widest_supported_shapes_match_oracle(zg, batch):
+    """n_embed = 2048 is the model tier's limit (4 E = 8192 floats of mlp input): LayerNorm strips of 512
+    float4, K = 8192 rows, batched rows that only fit the LDS in groups."""
+    cfg = synth.CONFIGS["max-slice"]
+    m, w = make(cfg, 95, batch=batch)
+    prompts = [synth.rand_tokens(950 + b, 1 + (3 * b) % 6, cfg.vocab_size) for b in range(batch)]
+    n_steps = 24
+    ids = m.generate(prompts, n_steps)
+    for b in range(batch):
+        ids_ref, lg = oracle.GPT(cfg, w).generate_greedy(prompts[b], n_steps, want_logits=True)
+        top = np.sort(lg, axis=1)
+        n = len(prompts[b])
+        assert_greedy_ids_match(ids_ref[n:], ids[b, n:], top[:, -1], top[:, -2], f"max-slice row {b}")
+    toks = np.stack([synth.rand_tokens(960 + b, 34, cfg.vocab_size) for b in range(batch)])
+    lg = m.prefill(toks[:, :33])
+    lg_ref = oracle.GPT(cfg, w).forced_logits(toks[0], 32)
+    assert_model_close(lg_ref[0], lg[0], "max-slice prefill")
+    m.close()
+    with pytest.raises(Exception):
+        zgpt.GPT(synth.GPTConfig(100, 16, 1, 33, 2112))  # beyond the limit: refused at creation
+
+
+def test_prompt_as_long_as_the_context(zg):
+    cfg = synth.CONFIGS["tiny"]
+    m, w = make(cfg, 96, batch=2)
+    prompts = [synth.rand_tokens(961, cfg.context_size, cfg.vocab_size), synth.rand_tokens(962, cfg.context_size - 1, cfg.vocab_size)]
+    ids = m.generate(prompts, cfg.context_size)
+    assert np.array_equal(ids[0], prompts[0])
+    ids_ref = oracle.GPT(cfg, w).generate_greedy(prompts[1], cfg.context_size)
+    assert np.array_equal(ids[1], ids_ref)
+    m.close()

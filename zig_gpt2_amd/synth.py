@@ -105,6 +105,7 @@ CONFIGS = {
     "tiny": GPTConfig(257, 64, 2, 2, 128),  # test-only
     "tiny3": GPTConfig(131, 48, 3, 3, 192),  # test-only, odd sizes
     "xl-slice": GPTConfig(1031, 96, 2, 25, 1600),  # test-only: GPT-2 XL's layer shapes (E = 1600, 25 heads), 2 layers
+    "max-slice": GPTConfig(515, 72, 1, 32, 2048),  # test-only: the widest supported model (4 E = 8192), 1 layer
 }
 
 BLOCK_TENSORS = [
