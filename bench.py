@@ -90,8 +90,15 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
     a = t_lo - b * c_lo
     mean_cost = a + b * (ctx + 1) / 2
     oracle.use_cblas(None)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
     return {
         "value": round(1.0 / mean_cost, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model, "visible_cpus": os.cpu_count(), "blas": blas,
         "sample": f"oracle GPT.forward fp32, {blas}: {n_win} tokens at T={lo0}.. ({1e3 * t_lo:.1f} ms/tok) and "
                   f"{n_win} at T={hi0}.. ({1e3 * t_hi:.1f} ms/tok); whole 1..{ctx} run priced by the affine fit",
     }
