@@ -317,17 +317,24 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
     const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
     const int B = (int)g->batch, M = (int)(g->batch * P), iE = (int)E;
     ZG_TRY(launch_embed_prefill(g->prompt, (int)C, B, (int)P, g->wte, g->wpe, g->wt, iE, g->pf_x, s));
+    ZG_TRY(launch_ln_split(g->pf_x, M, iE, g->layers[0].ln_1_g, g->layers[0].ln_1_b, 1e-5f, g->pf_a, s));
     for (size_t l = 0; l < L; ++l) {
         const zg_layer& y = g->layers[l];
-        ZG_TRY(launch_ln_split(g->pf_x, M, iE, y.ln_1_g, y.ln_1_b, 1e-5f, g->pf_a, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_F32, g->pf_ws, g->pf_ws_floats, s));
+        // pf_a holds split(ln_1(x)) here: from the line above or from the tail of the previous Block's last GEMM
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_F32,
+                                   g->pf_ws, g->pf_ws_floats, nullptr, s));
         ZG_TRY(launch_kv_scatter(g->pf_qkv, B, (int)P, iE, (int)H, (int)C, y.k_cache, y.v_cache, g->kv_f16, s));
         if (l + 1 == L && !last_block_full) break;
         ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws, g->pf_ws_floats, s));
-        ZG_TRY(launch_ln_split(g->pf_x, M, iE, y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, g->pf_ws, g->pf_ws_floats, s));
-        ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws, g->pf_ws_floats, s));
+        const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
+                                   g->pf_ws_floats, &ln2, s));
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, g->pf_ws,
+                                   g->pf_ws_floats, nullptr, s));
+        const bool more = l + 1 < L;
+        const PrefillLn ln1{more ? g->layers[l + 1].ln_1_g : nullptr, more ? g->layers[l + 1].ln_1_b : nullptr, 1e-5f, g->pf_a};
+        ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws,
+                                   g->pf_ws_floats, more ? &ln1 : nullptr, s));
     }
     return ZG_OK;
 }

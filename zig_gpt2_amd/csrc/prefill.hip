@@ -25,6 +25,8 @@
 
 namespace zg {
 
+int launch_ln_split(const float* x, int M, int E, const float* g, const float* b, float eps, bf16_t* out, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -266,9 +268,68 @@ __global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __rest
     }
 }
 
+// Split-K tail of a residual GEMM fused with the LayerNorm that follows it (main.zig:139-140 / the next
+// Block's ln_1): one workgroup per row, a float4 (two beyond E = 1024) per thread — the slices are summed in
+// fixed order, bias and the residual stream added, x stored, then the row it just produced is normalised and
+// written as the three bf16 planes of the next GEMM.  Two launches (reduce, ln_split) become one.
+__global__ __launch_bounds__(256) void prefill_reduce_resid_ln_kernel(const float* __restrict__ ws, int n_sp,
+                                                                      const float* __restrict__ bias, float* __restrict__ x,
+                                                                      int M, int N, const float* __restrict__ g,
+                                                                      const float* __restrict__ bta, float eps,
+                                                                      bf16_t* __restrict__ out) {
+    __shared__ float s_red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, n4 = N >> 2;
+    float* xr = x + (size_t)row * N;
+    f32x4 v[2];
+    float s = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j;
+        v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < n4) {
+            const int e = i * 4;
+            f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)row * N + e);
+            for (int sp = 1; sp < n_sp; ++sp) a += *reinterpret_cast<const f32x4*>(ws + ((size_t)sp * M + row) * N + e);
+            if (bias) a += *reinterpret_cast<const f32x4*>(bias + e);
+            a += *reinterpret_cast<const f32x4*>(xr + e);
+            *reinterpret_cast<f32x4*>(xr + e) = a;
+            v[j] = a;
+            s += (a.x + a.y) + (a.z + a.w);
+            ss += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        }
+    }
+    s = wave_allsum(s);
+    ss = wave_allsum(ss);
+    if ((tid & 63) == 0) {
+        s_red[(tid >> 6) * 2] = s;
+        s_red[(tid >> 6) * 2 + 1] = ss;
+    }
+    __syncthreads();
+    s = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
+    ss = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+    const float mean = s / (float)N;
+    const float sd = sqrtf(ss / (float)N - mean * mean + eps);
+    bf16_t* hi = out + (size_t)row * kSplit * N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j;
+        if (i < n4) {
+            const int e = i * 4;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + e);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + e);
+            f32x4 o;
+            o.x = (v[j].x - mean) / sd * gg.x + bb.x;
+            o.y = (v[j].y - mean) / sd * gg.y + bb.y;
+            o.z = (v[j].z - mean) / sd * gg.z + bb.z;
+            o.w = (v[j].w - mean) / sd * gg.w + bb.w;
+            store_split4(hi + e, N, o);
+        }
+    }
+}
+
 template <int EPI, int NS>
 int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                           float* ws, size_t ws_floats, hipStream_t s) {
+                           float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s) {
     static bool raised = false;
     if (!raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI, NS>),
@@ -293,11 +354,18 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
     } else {
         hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL, NS>), dim3(tiles, n_sp), dim3(256), lds_bytes(NS), s, A, B, bias,
                            (void*)ws, M, N, K, ldc, tiles_n, tiles);
+        if (EPI == PF_RESID && ln && ldc == N && N <= 2048) {
+            hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, n_sp, bias,
+                               reinterpret_cast<float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        }
         const size_t n = (size_t)M * (N / 4);
         hipLaunchKernelGGL((prefill_reduce_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n_sp, bias, C,
                            M, N, ldc);
     }
     ZG_HIP(hipGetLastError());
+    if (EPI == PF_RESID && ln) return launch_ln_split(reinterpret_cast<const float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out, s);
     return ZG_OK;
 }
 
@@ -305,12 +373,12 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
 // 157 FLOP per staged byte against 96) once there are enough rows to fill the chip with them, else 128 x 128.
 template <int EPI>
 int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                          float* ws, size_t ws_floats, hipStream_t s) {
+                          float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s) {
     static const int wide_env = getenv("ZGPT2_PF_WIDE") ? atoi(getenv("ZGPT2_PF_WIDE")) : -1;
     const int wide_tiles = ((M + BM - 1) / BM) * ((N + 2 * BN - 1) / (2 * BN));
     const bool wide = wide_env >= 0 ? wide_env != 0 : (wide_tiles >= 256 && N >= 2 * BN);
-    if (wide) return launch_prefill_gemm_ns<EPI, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
-    return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
+    if (wide) return launch_prefill_gemm_ns<EPI, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, s);
+    return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, s);
 }
 
 // ------------------------------------------------------------------------------------------ KV scatter
@@ -536,12 +604,12 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 }
 
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
-                        float* ws, size_t ws_floats, hipStream_t s) {
+                        float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
     switch (epi) {
-        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
-        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
-        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, s);
+        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, s);
+        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, s);
+        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, s);
     }
     ZG_REQUIRE(false, ZG_ERR_ARG, "prefill gemm: epilogue %d", epi);
 }

@@ -110,9 +110,17 @@ int launch_embed_prefill(const int* tokens, int token_stride, int B, int P, cons
                          int weight_type, int E, float* x, hipStream_t s);
 int launch_ln_split(const float* x, int M, int E, const float* g, const float* b, float eps, bf16_t* out, hipStream_t s);
 // C = A[M][kSplit K] * W[N][K]^T + bias; PF_F32: fp32 C[M][ldc]; PF_RESID: C += ...; PF_GELU_SPLIT: bf16 C[M][kSplit N] = split(gelu(...))
-// ws: fp32 workspace for split-K partial sums (used when the output has too few tiles to fill the chip)
+// ws: fp32 workspace for split-K partial sums (used when the output has too few tiles to fill the chip).
+// ln (PF_RESID only, may be null): LayerNorm of the updated rows, written as split planes to ln->out — fused
+// into the split-K tail when there is one, a separate launch_ln_split otherwise.
+struct PrefillLn {
+    const float* g;
+    const float* b;
+    float eps;
+    bf16_t* out;
+};
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
-                        float* ws, size_t ws_floats, hipStream_t s);
+                        float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s);
 int launch_kv_scatter(const float* qkv, int B, int P, int E, int H, int ctx, void* k_cache, void* v_cache, int kv_f16,
                       hipStream_t s);
 // out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t)
