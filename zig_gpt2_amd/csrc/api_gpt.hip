@@ -321,9 +321,10 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
     for (size_t l = 0; l < L; ++l) {
         const zg_layer& y = g->layers[l];
         // pf_a holds split(ln_1(x)) here: from the line above or from the tail of the previous Block's last GEMM
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_F32,
-                                   g->pf_ws, g->pf_ws_floats, nullptr, s));
-        ZG_TRY(launch_kv_scatter(g->pf_qkv, B, (int)P, iE, (int)H, (int)C, y.k_cache, y.v_cache, g->kv_f16, s));
+        // c_attn with the cache append of ops.zig:152-157 in its epilogue
+        const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_f16, y.k_cache, y.v_cache};
+        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
+                                   g->pf_ws, g->pf_ws_floats, nullptr, s, &qa));
         if (l + 1 == L && !last_block_full) break;
         ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
         const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};

@@ -16,7 +16,7 @@
 //   prefill_gemm       128 x 128 (or 128 x 256) x 64 tile, weight tile shared by the three planes, LDS-DMA double
 //                      buffer, epilogues:
 //                        F32 store | fp32 residual add | GELU + split        (ops.zig:21-46, main.zig:136-145, :79-80)
-//   kv_scatter         K / V columns of the qkv rows -> head-major caches    (src/ops.zig:152-158)
+//   (cache append)     K / V columns of the qkv rows -> head-major caches, in the c_attn GEMM epilogue (ops.zig:152-158)
 //   attn_prefill       causal softmax(q k^T / 8) v, flash style, transposed so that every per-query
 //                      statistic lives in one lane                           (src/ops.zig:249-307)
 #include <stdlib.h>
@@ -105,6 +105,22 @@ __global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__
     }
 }
 
+// Cache append for four consecutive columns [n, n + 4) >= E of qkv row m (PF_QKV epilogue).
+__device__ __forceinline__ void qkv_cache_store(const PrefillQkv& q, int m, int n, f32x4 v) {
+    if (n < q.E) return;
+    const int which = n >= 2 * q.E;
+    const int e = n - (which ? 2 * q.E : q.E);
+    const int b = m / q.P, t = m - b * q.P;
+    const size_t off = (((size_t)b * q.H + (e >> 6)) * q.ctx + t) * 64 + (e & 63);
+    void* cache = which ? q.v_cache : q.k_cache;
+    if (q.kv_f16) {
+        _Float16* d = reinterpret_cast<_Float16*>(cache) + off;
+        d[0] = (_Float16)v.x; d[1] = (_Float16)v.y; d[2] = (_Float16)v.z; d[3] = (_Float16)v.w;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(cache) + off) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ GEMM
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;
@@ -145,7 +161,8 @@ __device__ __forceinline__ float gelu_fast(float x) {
 template <int EPI, int NS>  // NS 64-column strips per wave: the tile is 128 x (128 NS)
 __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                               const float* __restrict__ bias, void* __restrict__ C, int M,
-                                                              int N, int K, int ldc, int tiles_n, int n_tiles) {
+                                                              int N, int K, int ldc, int tiles_n, int n_tiles,
+                                                              const PrefillQkv qa) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -241,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
                 float* dst = reinterpret_cast<float*>(C) + (size_t)gm * ldc + nw + cc * 4;
                 if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
                 *reinterpret_cast<f32x4*>(dst) = v;
+                if (EPI == PF_QKV) qkv_cache_store(qa, gm, nw + cc * 4, v);
             }
         }
     }
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
 template <int EPI>
 __global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __restrict__ ws, int n_sp,
                                                              const float* __restrict__ bias, void* __restrict__ C, int M,
-                                                             int N, int ldc) {
+                                                             int N, int ldc, const PrefillQkv qa) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int n4 = N / 4;
     if (i >= (size_t)M * n4) return;
@@ -265,6 +283,7 @@ __global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __rest
         float* dst = reinterpret_cast<float*>(C) + (size_t)m * ldc + n;
         if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
+        if (EPI == PF_QKV) qkv_cache_store(qa, m, n, v);
     }
 }
 
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(256) void prefill_reduce_resid_ln_kernel(const floa
 
 template <int EPI, int NS>
 int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                           float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s) {
+                           float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, hipStream_t s) {
     static bool raised = false;
     if (!raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI, NS>),
@@ -350,10 +369,10 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
     if (force > 0) n_sp = force;
     if (n_sp <= 1 || !ws) {
         hipLaunchKernelGGL((prefill_gemm_kernel<EPI, NS>), dim3(tiles), dim3(256), lds_bytes(NS), s, A, B, bias, C, M, N, K,
-                           ldc, tiles_n, tiles);
+                           ldc, tiles_n, tiles, qa);
     } else {
         hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL, NS>), dim3(tiles, n_sp), dim3(256), lds_bytes(NS), s, A, B, bias,
-                           (void*)ws, M, N, K, ldc, tiles_n, tiles);
+                           (void*)ws, M, N, K, ldc, tiles_n, tiles, qa);
         if (EPI == PF_RESID && ln && ldc == N && N <= 2048) {
             hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, n_sp, bias,
                                reinterpret_cast<float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out);
@@ -362,7 +381,7 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
         }
         const size_t n = (size_t)M * (N / 4);
         hipLaunchKernelGGL((prefill_reduce_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n_sp, bias, C,
-                           M, N, ldc);
+                           M, N, ldc, qa);
     }
     ZG_HIP(hipGetLastError());
     if (EPI == PF_RESID && ln) return launch_ln_split(reinterpret_cast<const float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out, s);
@@ -373,33 +392,12 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
 // 157 FLOP per staged byte against 96) once there are enough rows to fill the chip with them, else 128 x 128.
 template <int EPI>
 int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                          float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s) {
+                          float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, hipStream_t s) {
     static const int wide_env = getenv("ZGPT2_PF_WIDE") ? atoi(getenv("ZGPT2_PF_WIDE")) : -1;
     const int wide_tiles = ((M + BM - 1) / BM) * ((N + 2 * BN - 1) / (2 * BN));
     const bool wide = wide_env >= 0 ? wide_env != 0 : (wide_tiles >= 256 && N >= 2 * BN);
-    if (wide) return launch_prefill_gemm_ns<EPI, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, s);
-    return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, s);
-}
-
-// ------------------------------------------------------------------------------------------ KV scatter
-// qkv row m = b P + t, columns [E, 2E) -> k_cache[b][h][t][d], [2E, 3E) -> v_cache (the cache rows the
-// reference appends at ops.zig:152,157; head-major here so that decode needs no transpose).
-template <typename KV>
-__global__ __launch_bounds__(256) void kv_scatter_kernel(const float* __restrict__ qkv, int P, int E, int H, int ctx,
-                                                         KV* __restrict__ kc, KV* __restrict__ vc, size_t total4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int e4 = (int)(i % (size_t)(E / 4)) * 4;
-    const size_t rest = i / (size_t)(E / 4);
-    const int which = (int)(rest & 1);
-    const size_t m = rest >> 1;
-    const int b = (int)(m / P), t = (int)(m % P), h = e4 / 64, d = e4 % 64;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + m * 3 * E + (which ? 2 * E : E) + e4);
-    KV* dst = (which ? vc : kc) + (((size_t)b * H + h) * ctx + t) * 64 + d;
-    dst[0] = (KV)v.x;
-    dst[1] = (KV)v.y;
-    dst[2] = (KV)v.z;
-    dst[3] = (KV)v.w;
+    if (wide) return launch_prefill_gemm_ns<EPI, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
+    return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
 }
 
 // ------------------------------------------------------------------------------------------ attention
@@ -604,28 +602,18 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 }
 
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
-                        float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s) {
+                        float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
+    const PrefillQkv none{};
     switch (epi) {
-        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, s);
-        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, s);
-        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, s);
+        case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, none, s);
+        case PF_RESID: return launch_prefill_gemm_t<PF_RESID>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, none, s);
+        case PF_GELU_SPLIT: return launch_prefill_gemm_t<PF_GELU_SPLIT>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, none, s);
+        case PF_QKV:
+            ZG_REQUIRE(qkv && N == 3 * qkv->E && ldc == N, ZG_ERR_ARG, "prefill gemm: PF_QKV needs the cache description");
+            return launch_prefill_gemm_t<PF_QKV>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, *qkv, s);
     }
     ZG_REQUIRE(false, ZG_ERR_ARG, "prefill gemm: epilogue %d", epi);
-}
-
-int launch_kv_scatter(const float* qkv, int B, int P, int E, int H, int ctx, void* k_cache, void* v_cache, int kv_f16,
-                      hipStream_t s) {
-    const size_t total4 = (size_t)B * P * 2 * (E / 4);
-    const unsigned grid = (unsigned)((total4 + 255) / 256);
-    if (kv_f16)
-        hipLaunchKernelGGL(kv_scatter_kernel<_Float16>, dim3(grid), dim3(256), 0, s, qkv, P, E, H, ctx,
-                           reinterpret_cast<_Float16*>(k_cache), reinterpret_cast<_Float16*>(v_cache), total4);
-    else
-        hipLaunchKernelGGL(kv_scatter_kernel<float>, dim3(grid), dim3(256), 0, s, qkv, P, E, H, ctx,
-                           reinterpret_cast<float*>(k_cache), reinterpret_cast<float*>(v_cache), total4);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
 }
 
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s) {

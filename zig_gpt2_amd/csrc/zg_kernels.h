@@ -105,7 +105,7 @@ int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, voi
 // Whole-prompt forward.  Activations feeding a GEMM are fp32 split exactly into kSplit bf16 terms,
 // stored as planes [M][kSplit * K] = [hi | mid | lo].
 constexpr int kSplit = 3;
-enum PrefillEpilogue { PF_F32 = 0, PF_RESID = 1, PF_GELU_SPLIT = 2, PF_PARTIAL = 3 /* internal: split-K slice */ };
+enum PrefillEpilogue { PF_F32 = 0, PF_RESID = 1, PF_GELU_SPLIT = 2, PF_PARTIAL = 3 /* internal: split-K slice */, PF_QKV = 4 };
 int launch_embed_prefill(const int* tokens, int token_stride, int B, int P, const void* wte, const void* wpe,
                          int weight_type, int E, float* x, hipStream_t s);
 int launch_ln_split(const float* x, int M, int E, const float* g, const float* b, float eps, bf16_t* out, hipStream_t s);
@@ -113,6 +113,13 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 // ws: fp32 workspace for split-K partial sums (used when the output has too few tiles to fill the chip).
 // ln (PF_RESID only, may be null): LayerNorm of the updated rows, written as split planes to ln->out — fused
 // into the split-K tail when there is one, a separate launch_ln_split otherwise.
+// PF_QKV: fp32 store of the qkv rows (row m = b P + t) AND the cache append of ops.zig:152-157 for the K / V
+// columns, into the head-major caches [b][h][ctx][64] (fp32 or fp16).
+struct PrefillQkv {
+    int P, E, H, ctx, kv_f16;
+    void* k_cache;
+    void* v_cache;
+};
 struct PrefillLn {
     const float* g;
     const float* b;
@@ -120,9 +127,7 @@ struct PrefillLn {
     bf16_t* out;
 };
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
-                        float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s);
-int launch_kv_scatter(const float* qkv, int B, int P, int E, int H, int ctx, void* k_cache, void* v_cache, int kv_f16,
-                      hipStream_t s);
+                        float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv = nullptr);
 // out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t)
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s);
 
