@@ -10,7 +10,7 @@
 // K and V loads (16 B per lane, 16 lanes per 256-B row, fully coalesced) before any arithmetic.
 // Scores are reduced across the 16 lanes of a row with a DPP butterfly reduce-scatter so that
 // every lane ends up owning one position; the softmax statistics are wave reductions; the
-// probabilities are handed back to the lanes that hold the matching V rows with ds_bpermute.
+// probabilities are handed back to the lanes that hold the matching V rows with DPP row broadcasts.
 // Four waves (256 positions) are merged in LDS; partials (o[64], m, l) of the <= ctx/256 splits
 // per head are combined by the consumer (the c_proj GEMV prologue, or attn_merge_kernel).
 #include "zg_kernels.h"
@@ -140,14 +140,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         const float p = (t_mine < T) ? __expf(sc - m_w) : 0.0f;
         l_w = wave_allsum(p);
         // ---- o += p_t * V_t ; p of position (i, g) lives in lane g*16 + i
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float pi = __shfl(p, (g << 4) + i, 64);
-            o4.x = fmaf(pi, v4[i].x, o4.x);
-            o4.y = fmaf(pi, v4[i].y, o4.y);
-            o4.z = fmaf(pi, v4[i].z, o4.z);
-            o4.w = fmaf(pi, v4[i].w, o4.w);
-        }
+        // lane i of each 16-lane row to the whole row: DPP row_newbcast, no LDS crossbar
+#define ZG_PV(i)                                                                                                         \
+    {                                                                                                                    \
+        const float pi = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x150 + (i), 0xF, 0xF, false)); \
+        o4.x = fmaf(pi, v4[i].x, o4.x);                                                                                  \
+        o4.y = fmaf(pi, v4[i].y, o4.y);                                                                                  \
+        o4.z = fmaf(pi, v4[i].z, o4.z);                                                                                  \
+        o4.w = fmaf(pi, v4[i].w, o4.w);                                                                                  \
+    }
+        ZG_PV(0) ZG_PV(1) ZG_PV(2) ZG_PV(3) ZG_PV(4) ZG_PV(5) ZG_PV(6) ZG_PV(7)
+        ZG_PV(8) ZG_PV(9) ZG_PV(10) ZG_PV(11) ZG_PV(12) ZG_PV(13) ZG_PV(14) ZG_PV(15)
+#undef ZG_PV
         // sum the four position groups (lanes 16 apart)
         o4.x += __shfl_xor(o4.x, 16, 64); o4.y += __shfl_xor(o4.y, 16, 64);
         o4.z += __shfl_xor(o4.z, 16, 64); o4.w += __shfl_xor(o4.w, 16, 64);
