@@ -2,21 +2,30 @@
 //   C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (optionally GELU), bf16 operands, fp32 accumulate.
 //
 // This is Linear.forward (reference src/ops.zig:21-46: cblas_sgemm RowMajor/NoTrans/Trans) for
-// M >> 1 — prompt prefill and the BASELINE "768x3072 GEMM" point (c_fc: K = 768, N = 3072).  Both
-// operands are K-contiguous ("NT"), exactly the layouts ops.Linear already uses (x is [M, in], weight
-// is [out, in]), so neither needs a transpose: an MFMA A fragment is 8 consecutive k of one row of x
-// and a B fragment is 8 consecutive k of one row of W.
+// M >> 1 — zg_linear_forward at M >= 16, the prompt prefill GEMMs and the BASELINE "768x3072 GEMM" point
+// (c_fc: K = 768, N = 3072).  Both operands are K-contiguous ("NT"), exactly the layouts ops.Linear
+// already uses (x is [M, in], weight is [out, in]), so neither needs a transpose.
 //
-// Structure: 128 x 128 x 64 tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2
-// v_mfma_f32_32x32x16_bf16 tiles, 64 accumulator VGPRs), two LDS stages of 32 KiB filled by
-// global_load_lds_dwordx4 (16 B per lane straight into LDS, no VGPR round trip), XOR-swizzled so
-// that the ds_read_b128 fragment reads are bank-conflict free: a tile row is 128 B = 8 chunks of
-// 16 B and chunk c of row r is stored at position c ^ ((r >> 1) & 7).  Because the LDS-DMA writes
-// lane-linearly, the swizzle is applied to the per-lane global SOURCE address and again on the
-// fragment read (guide rule: both sides or neither).  Workgroups are renumbered so that the 8 XCDs
-// (private L2s) each own a contiguous range of output tiles.  The epilogue stages the wave's
-// 64 x 64 tile through LDS and writes full 128-B row segments with 16-B stores.
+// One kernel family, `gemm_p8_kernel<BN, ...>`:
+//   * PERSISTENT: at most 256 workgroups (one per CU) walk the output tiles; tile shape 256 x BN with
+//     BN in {256, 192} picked per problem so that the tile count divides over the CUs (M = 8192, N = 3072:
+//     512 tiles of 256 x 192 = exactly two per CU instead of 1.5 tiles of 256 x 256).
+//   * 8 waves, 512 threads, 16x16x32 bf16 MFMAs with the operands SWAPPED (A operand = weight rows, B
+//     operand = activation rows), so a lane's four accumulator values are four consecutive output COLUMNS
+//     of one row: the epilogue packs them into one 8-byte LDS write and the tile leaves as full-line rows.
+//   * K-step of 64, two LDS buffers of four "half-tile units" (A rows of quadrant-half 0 / 1 of every
+//     wave, B rows likewise), each unit filled by LDS-DMA (buffer_load ... lds, 16 B per lane, out-of-range
+//     rows read as zero so M and N need not be tile multiples).  The image is XOR-swizzled on the SOURCE
+//     side (the DMA writes lane-linearly) and on the fragment read: ds_read_b128 is conflict free.
+//   * 4 phases per K-step (one accumulator quadrant each), every phase = {fragment reads + one unit of DMA,
+//     s_barrier, MFMAs, s_barrier}; the two waves of a SIMD belong to two groups staggered by one barrier,
+//     so one of them multiplies while the other loads.  DMA runs four units (a whole K-step) ahead under
+//     COUNTED vmcnt waits; the stream of units continues across tile boundaries, i.e. the next tile's
+//     first K-steps land while the current tile's epilogue runs.
+//   * XCD-aware tile order: each XCD (private 4-MiB L2) owns a contiguous range of a column-banded order.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "zg_kernels.h"
 
@@ -24,167 +33,9 @@ namespace zg {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int kStageBytes = 2 * kTileBytes;      // A + B
-constexpr int kLdsBytes = 2 * kStageBytes;       // double buffered: 64 KiB
-
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-// Fill one 128 x 64 bf16 operand tile: 16 wave-instructions of 1 KiB, 4 per wave.
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int k0, char* lds_tile,
-                                           int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave * 4 + q;               // 1-KiB piece = 8 tile rows
-        const int row = piece * 8 + (lane >> 3);      // tile row this lane fills
-        const int pos = lane & 7;                     // chunk position inside the LDS row
-        const int chunk = pos ^ ((row >> 1) & 7);     // which source chunk belongs there
-        const bf16_t* src = G + (size_t)(row0 + row) * ld + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
-    const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + off);
-}
-
-template <bool GELU, bool OUT_BF16>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ A,
-                                                              const bf16_t* __restrict__ B,
-                                                              const float* __restrict__ bias, void* __restrict__ C,
-                                                              int M, int N, int K, int ldc, int tiles_n,
-                                                              int n_tiles) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware renumbering (bijective for any tile count): XCD x = bid % 8 owns a contiguous range.
-    const int bid = blockIdx.x;
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nt = K / BK;
-    stage_tile(A, K, m0, 0, lds, wave, lane);
-    stage_tile(B, K, n0, 0, lds + kTileBytes, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    __syncthreads();
-
-    const int frow = lane & 31, fk = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        char* cur = lds + (t & 1) * kStageBytes;
-        if (t + 1 < nt) {
-            char* nxt = lds + ((t + 1) & 1) * kStageBytes;
-            stage_tile(A, K, m0, (t + 1) * BK, nxt, wave, lane);
-            stage_tile(B, K, n0, (t + 1) * BK, nxt + kTileBytes, wave, lane);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = read_frag(cur, wm * 64 + i * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = read_frag(cur + kTileBytes, wn * 64 + j * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): next stage landed
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias (+ GELU), convert, stage the wave's 64 x 64 tile in LDS, 16-B row stores
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
-    char* wtile = lds + wave * (64 * 64 * ESZ);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j * 32 + frow;
-        const float bv = bias ? bias[n0 + wn * 64 + col] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                float v = acc[i][j][r] + bv;
-                if (GELU) v = gelu_ref(v);
-                if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = f32_to_bf16_rne(v);
-                else reinterpret_cast<float*>(wtile)[row * 64 + col] = v;
-            }
-    }
-    // each wave re-reads only its own strip: wave-local ordering suffices
-    constexpr int ROW_BYTES = 64 * ESZ, CHUNKS_PER_ROW = ROW_BYTES / 16, CHUNKS = 64 * CHUNKS_PER_ROW;
-#pragma unroll
-    for (int it = 0; it < CHUNKS / 64; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + row * ROW_BYTES + cc * 16);
-        char* dst = reinterpret_cast<char*>(C) + ((size_t)(m0 + wm * 64 + row) * ldc + n0 + wn * 64) * ESZ + cc * 16;
-        *reinterpret_cast<u32x4*>(dst) = v;
-    }
-}
-
-template <bool GELU, bool OUT_BF16>
-int launch_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                  hipStream_t s) {
-    static bool raised = false;
-    if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<GELU, OUT_BF16>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        raised = true;
-    }
-    const int tiles_m = M / BM, tiles_n = N / BN;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<GELU, OUT_BF16>), dim3(tiles_m * tiles_n), dim3(256), kLdsBytes, s, A, B,
-                       bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Deep-pipelined variant: 256 x 128 x 64 tile, 8 waves (4 x 2, each 64 x 64), one workgroup per CU,
-// a 3-slot LDS ring (3 x 48 KiB) filled two K-steps ahead by LDS-DMA.  The loop has ONE raw
-// s_barrier per K-step and counted vmcnt (never 0 in steady state), so the DMA of stages t+1 / t+2
-// stays in flight across the barrier while stage t is multiplied:
-//     wait vmcnt(6)  -> this wave's pieces of stage t landed (stage t+1's 6 may still fly)
-//     s_barrier      -> everybody's pieces landed AND everybody finished reading slot (t-1) % 3
-//     issue stage t+2 into slot (t+2) % 3 == (t-1) % 3
-//     ds_read + MFMA on slot t % 3
-// All LDS is one array and no ordinary global load lives in the loop (hipcc otherwise drains the DMA
-// queue with vmcnt(0)); bias is fetched in the epilogue.
-constexpr int DM = 256, DN = 128;
-constexpr int kDeepStage = (DM + DN) * BK * 2;  // 48 KiB
-constexpr int kDeepLds = 3 * kDeepStage;        // 144 KiB
-
-// rows: DM (A, 32 pieces) then DN (B, 16 pieces): 48 one-KiB pieces per stage, 6 per wave.
-__device__ __forceinline__ void stage_deep(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int K, int m0,
-                                           int n0, int k0, char* slot, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int piece = wave * 6 + q;                 // 0..47
-        const bool isB = piece >= 32;
-        const int prow = (isB ? piece - 32 : piece) * 8 + (lane >> 3);  // row inside its tile
-        const int pos = lane & 7;
-        const int chunk = pos ^ ((prow >> 1) & 7);
-        const bf16_t* src = (isB ? B + (size_t)(n0 + prow) * K : A + (size_t)(m0 + prow) * K) + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(slot + piece * 1024), 16, 0, 0);
-    }
-}
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 // gelu(x) = x / (1 + exp(-2u)), u = x * 0.7978845608 * (1 + 0.044715 x^2)  (src/ops.zig:225), with the
 // -2 log2(e) factor folded into the polynomial so that the exponential is a bare v_exp_f32.
@@ -194,544 +45,388 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
 }
 
-// fp32 -> bf16 (round to nearest even) in one instruction (gfx950 v_cvt_pk_bf16_f32).
-__device__ __forceinline__ bf16_t cvt_bf16(float x) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return (bf16_t)r;
+template <int BN_>
+struct P8 {
+    static constexpr int BM = 256, BN = BN_, BK = 64;
+    static constexpr int WM = (BN == 256) ? 2 : 4, WN = 8 / WM;  // waves along M / N
+    static constexpr int TM = BM / WM, TN = BN / WN;             // wave tile
+    static constexpr int MT = TM / 16, NT = TN / 16;             // 16x16 MFMA tiles per wave
+    static constexpr int QM = MT / 2, QN = NT / 2;               // per accumulator quadrant
+    static constexpr int A_UNIT = 128 * 128;                     // bytes: 128 rows x 64 k bf16
+    static constexpr int B_UNIT = (BN / 2) * 128;
+    static constexpr int BUF = 2 * A_UNIT + 2 * B_UNIT;
+    static constexpr int B_PIECES = B_UNIT / 1024;               // 1-KiB DMA pieces per B unit: 16 or 12
+    static constexpr int ST_ROW = TN * 2 + 16;                   // padded staging row (bytes)
+    static constexpr int ST_WAVE = 16 * ST_ROW;
+    static constexpr int ST_OFF = 2 * BUF;
+    static constexpr int LDS = ST_OFF + 8 * ST_WAVE;
+    static constexpr int W = 4 + 2 * B_PIECES / 8;               // DMA instructions per wave per K-step: 8 or 7
+    static __device__ __host__ constexpr int off_a(int h) { return h * A_UNIT; }
+    static __device__ __host__ constexpr int off_b(int h) { return 2 * A_UNIT + h * B_UNIT; }
+};
+
+// NTILE fragments pairs (kk = 0 / 1) of one unit: tile i sits 16 rows = 2048 B further; hand-issued so that the
+// reads stay where they are written (the compiler's own LDS loads may move across s_barrier)
+template <int NTILE, int OFF>
+__device__ __forceinline__ void read_frags(bf16x8 (&f)[NTILE * 2], unsigned addr0, unsigned addr1) {
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i * 2 + 0]) : "v"(addr0), "i"(OFF + i * 2048));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i * 2 + 1]) : "v"(addr1), "i"(OFF + i * 2048));
+    }
 }
 
-template <bool GELU, bool OUT_BF16>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_deep_kernel(const bf16_t* __restrict__ A,
-                                                                   const bf16_t* __restrict__ B,
-                                                                   const float* __restrict__ bias,
-                                                                   void* __restrict__ C, int M, int N, int K, int ldc,
-                                                                   int tiles_n, int n_tiles) {
+#define ZG_SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ lds_ptr_t to_lds(unsigned byte_addr) { return (lds_ptr_t)(size_t)byte_addr; }
+
+// tile index in the column-banded order -> (tm, tn): bands of `gw` N-tiles, M-major inside a band, so an
+// XCD's contiguous range is a block of (few M-tiles) x (gw N-tiles) whose panels stay in its L2.
+__device__ __forceinline__ void tile_of(int idx, int tiles_m, int tiles_n, int gw, int& tm, int& tn) {
+    const int band = idx / (tiles_m * gw), full = tiles_n / gw;
+    if (band < full) {
+        const int r = idx - band * tiles_m * gw;
+        tm = r / gw;
+        tn = band * gw + r % gw;
+    } else {
+        const int w = tiles_n - full * gw, r = idx - full * tiles_m * gw;
+        tm = r / w;
+        tn = full * gw + r % w;
+    }
+}
+
+template <int BN, bool GELU, bool OUT_BF16>
+__global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         const float* __restrict__ bias, void* __restrict__ C, int M,
+                                                         int N, int K, int ldc, int tiles_m, int tiles_n, int gw) {
+    using P = P8<BN>;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2;  // waves w and w + 4 share a SIMD: one of each group per SIMD
+    const int wr = wave / P::WN, wc = wave % P::WN;
+    const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)lds;
 
-    const int bid = blockIdx.x;
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
-    const int m0 = tm * DM, n0 = tn * DN;
+    // ---- this workgroup's tiles: XCD x = bid % 8 owns a contiguous range of the banded order
+    const int n_tiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
+    const int nx = G < 8 ? G : 8;  // XCD groups that have workgroups
+    const int xcd = bid % nx, loc = bid / nx;
+    const int gx = G / nx + (xcd < G % nx ? 1 : 0);
+    const int q8 = n_tiles / nx, r8 = n_tiles % nx;
+    const int t_begin = xcd * q8 + min(xcd, r8), t_end = t_begin + q8 + (xcd < r8 ? 1 : 0);
+    int idx = t_begin + loc;
+    if (idx >= t_end) return;
 
-    f32x16 acc[2][2];
+    // ---- DMA source descriptors and per-lane offsets (constant for the whole kernel, relative to a tile)
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+    // piece = 8 unit rows x 128 B; lane -> unit row r = piece * 8 + lane / 8, LDS position p = lane % 8 holds
+    // source chunk p ^ ((r >> 1) & 7)
+    auto rel_off = [&](int piece, int rows_per_wave_half, int tile_dim, int h) -> unsigned {
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int trow = (r / rows_per_wave_half) * tile_dim + h * rows_per_wave_half + r % rows_per_wave_half;
+        return (unsigned)(trow * K + c * 8) * 2u;
+    };
+    // Per operand ONE per-lane offset (piece `wave` of half 0); the wave's second piece and half 1 are whole rows
+    // further (the swizzle term repeats every 16 rows), i.e. wave-uniform byte deltas that go into the scalar
+    // tile base.  B-unit pieces per wave: BN = 256 -> {w, w + 8} for both halves; BN = 192 (12 pieces) ->
+    // half 0: {w, w + 8 if w < 4}, half 1: {w, w + 4 if w >= 4}: every wave issues W = 7 pieces per K-step.
+    const int pa1 = wave + 8;
+    const int pb1[2] = {wave + 8, BN == 256 ? wave + 8 : wave + 4};
+    const bool vb1[2] = {BN == 256 || wave < 4, BN == 256 || wave >= 4};
+    auto tile_row = [&](int r, int half_rows, int tile_dim, int h) {  // unit row -> row of the tile
+        return (r / half_rows) * tile_dim + h * half_rows + r % half_rows;
+    };
+    const unsigned relA = rel_off(wave, P::TM / 2, P::TM, 0), relB = rel_off(wave, P::TN / 2, P::TN, 0);
+    unsigned dA[2][2], dB[2][2];  // [half][piece slot] byte deltas (scalars)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nt = K / BK;
-    stage_deep(A, B, K, m0, n0, 0, lds, wave, lane);
-    if (nt > 1) stage_deep(A, B, K, m0, n0, BK, lds + kDeepStage, wave, lane);
-
-    const int frow = lane & 31, fk = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0f76);  // vmcnt(6): stage t landed, t+1 may fly
-        else __builtin_amdgcn_s_waitcnt(0x0f70);             // vmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) stage_deep(A, B, K, m0, n0, (t + 2) * BK, lds + ((t + 2) % 3) * kDeepStage, wave, lane);
-        const char* cur = lds + (t % 3) * kDeepStage;
-        const char* curB = cur + DM * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = read_frag(cur, wm * 64 + i * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = read_frag(curB, wn * 64 + j * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+    for (int h = 0; h < 2; ++h) {
+        const int ra0 = tile_row(wave * 8, P::TM / 2, P::TM, 0), rb0 = tile_row(wave * 8, P::TN / 2, P::TN, 0);
+        dA[h][0] = (unsigned)(tile_row(wave * 8, P::TM / 2, P::TM, h) - ra0) * (unsigned)K * 2u;
+        dA[h][1] = (unsigned)(tile_row(pa1 * 8, P::TM / 2, P::TM, h) - ra0) * (unsigned)K * 2u;
+        dB[h][0] = (unsigned)(tile_row(wave * 8, P::TN / 2, P::TN, h) - rb0) * (unsigned)K * 2u;
+        dB[h][1] = (unsigned)(tile_row(pb1[h] * 8, P::TN / 2, P::TN, h) - rb0) * (unsigned)K * 2u;
     }
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before it becomes the store staging area
 
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
-    char* wtile = lds + wave * (64 * 64 * ESZ);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j * 32 + frow;
-        const float bv = bias ? bias[n0 + wn * 64 + col] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                float v = acc[i][j][r] + bv;
-                if (GELU) v = gelu_fast(v);
-                if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = f32_to_bf16_rne(v);
-                else reinterpret_cast<float*>(wtile)[row * 64 + col] = v;
-            }
-    }
-    constexpr int ROW_BYTES = 64 * ESZ, CHUNKS_PER_ROW = ROW_BYTES / 16, CHUNKS = 64 * CHUNKS_PER_ROW;
-#pragma unroll
-    for (int it = 0; it < CHUNKS / 64; ++it) {
-        const int c = it * 64 + lane;
-        const int row = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + row * ROW_BYTES + cc * 16);
-        char* dst = reinterpret_cast<char*>(C) + ((size_t)(m0 + wm * 64 + row) * ldc + n0 + wn * 64) * ESZ + cc * 16;
-        *reinterpret_cast<u32x4*>(dst) = v;
-    }
-}
+    // ---- fragment read addresses: unit row = wr * TM/2 + i * 16 + (lane & 15), 16-B chunk kk * 4 + lane / 16
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned sw0 = (unsigned)((lq ^ ((lane >> 1) & 7)) << 4);
+    const unsigned a_addr0 = lds_base + (wr * (P::TM / 2) + l15) * 128 + sw0, a_addr1 = a_addr0 ^ 64u;
+    const unsigned b_addr0 = lds_base + (wc * (P::TN / 2) + l15) * 128 + sw0, b_addr1 = b_addr0 ^ 64u;
 
-template <bool GELU, bool OUT_BF16>
-int launch_gemm_deep_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                       hipStream_t s) {
-    static bool raised = false;
-    if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_deep_kernel<GELU, OUT_BF16>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kDeepLds));
-        raised = true;
-    }
-    const int tiles_m = M / DM, tiles_n = N / DN;
-    hipLaunchKernelGGL((gemm_nt_bf16_deep_kernel<GELU, OUT_BF16>), dim3(tiles_m * tiles_n), dim3(512), kDeepLds, s, A,
-                       B, bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// 256 x 256 x 32 variant.  Measured on this chip the LDS-staged kernels are bound by the global->LDS
-// fill rate per CU, so TFLOP/s scale with the tile's FLOP per staged byte: 128x128 = 65, 256x128 = 87,
-// 256x256 = 131 FLOP/B.  8 waves as 2 (M) x 4 (N), each 128 x 64 = 4 x 2 MFMA tiles (128 accumulator
-// VGPRs); a 4-slot ring of 32-KiB stages (BK = 32) filled three K-steps ahead; one raw s_barrier per
-// K-step, counted vmcnt(8).  A tile row is 64 B = 4 chunks of 16 B; chunk c of row r sits at position
-// c ^ ((r >> 2) & 3), which makes the 16-lane groups of ds_read_b128 conflict free.
-constexpr int QM = 256, QN = 256, QK = 32;
-constexpr int kQStage = (QM + QN) * QK * 2;  // 32 KiB
-constexpr int kQSlots = 5;                   // ring slots: 4 stages in flight + the one being multiplied
-constexpr int kQLds = kQSlots * kQStage;     // 160 KiB: the whole LDS of a CU
-
-__device__ __forceinline__ void stage_q(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int K, int m0,
-                                        int n0, int k0, char* slot, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave * 4 + q;                  // 0..31: 16 A pieces (16 rows each) then 16 B pieces
-        const bool isB = piece >= 16;
-        const int prow = (isB ? piece - 16 : piece) * 16 + (lane >> 2);
-        const int pos = lane & 3;
-        const int chunk = pos ^ ((prow >> 2) & 3);
-        const bf16_t* src = (isB ? B + (size_t)(n0 + prow) * K : A + (size_t)(m0 + prow) * K) + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(slot + piece * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ bf16x8 read_frag_q(const char* tile, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
-}
-
-template <bool GELU, bool OUT_BF16>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_q_kernel(const bf16_t* __restrict__ A,
-                                                                const bf16_t* __restrict__ B,
-                                                                const float* __restrict__ bias, void* __restrict__ C,
-                                                                int M, int N, int K, int ldc, int tiles_n, int n_tiles,
-                                                                int gw, int prio, int ablate) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int bid = blockIdx.x;
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    // Column-grouped order: the XCD's contiguous tile range walks down M inside a band of `gw` N-tiles,
-    // so the band's B panels stay resident in the XCD's 4-MiB L2 while A panels stream through once.
+    const int nt = K / 64;
     int tm, tn;
-    {
-        const int tiles_m = n_tiles / tiles_n;
-        const int band = tile / (tiles_m * gw);               // full bands first
-        const int full = tiles_n / gw;
-        if (band < full) {
-            const int r = tile - band * tiles_m * gw;
-            tm = r / gw;
-            tn = band * gw + r % gw;
-        } else {                                              // last, narrower band
-            const int w = tiles_n - full * gw;
-            const int r = tile - full * tiles_m * gw;
-            tm = r / w;
-            tn = full * gw + r % w;
-        }
+    tile_of(idx, tiles_m, tiles_n, gw, tm, tn);
+    unsigned curA = (unsigned)tm * 256u * (unsigned)K * 2u, curB = (unsigned)tn * BN * (unsigned)K * 2u;
+    int m0 = tm * 256, n0 = tn * BN;
+    constexpr unsigned kOob = 0x80000000u;  // tile base of "no next tile": every lane out of range -> zero fill
+    unsigned nxtA = kOob, nxtB = kOob;
+    int nidx = idx + gx;
+    int ntm = 0, ntn = 0;
+    if (nidx < t_end) {
+        tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
+        nxtA = (unsigned)ntm * 256u * (unsigned)K * 2u;
+        nxtB = (unsigned)ntn * BN * (unsigned)K * 2u;
     }
-    const int m0 = tm * QM, n0 = tn * QN;
-    // diagnostic (ZGPT2_ABLATE=8): stage every tile from the same panels (all-L2-hit upper bound)
-    const int ms = (ablate & 8) ? 0 : m0, ns = (ablate & 8) ? 0 : n0;
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nt = K / QK;
-#pragma unroll
-    for (int st = 0; st < kQSlots - 1; ++st)
-        if (st < nt) stage_q(A, B, K, ms, ns, st * QK, lds + st * kQStage, wave, lane);
-
-    const int frow = lane & 31, fk = lane >> 5;
-    // Role-split schedule.  The two waves that share a SIMD (w and w + 4) run half a stage out of phase:
-    // in every barrier interval one of them only reads its fragments of a stage from LDS into registers
-    // (12 ds_read_b128) while the other only issues that stage's 16 MFMAs, so the matrix pipe of each SIMD
-    // is fed continuously by alternating waves instead of both waves loading and then both multiplying
-    // (ablation: DMA, LDS reads and MFMA each take ~170-185 us of a 304 us lock-step run at 8192x4096x4096).
-    //   interval i (between barriers i and i+1):  group g runs phase p = i - g;
-    //   p even -> LOAD(stage p/2), p odd -> COMPUTE(stage (p-1)/2).
-    // Stage s is waited for (counted vmcnt) before barrier 2s; the DMA of stage s+3 is issued after
-    // barrier 2s into the slot whose last reader (group 1, interval 2s-1) has passed that barrier.
-    const int grp = wave >> 2;
-    bf16x8 fa[2][4], fb[2][2];
-    auto load_stage = [&](int stage) {
-        const char* cur = lds + (stage % kQSlots) * kQStage;
-        const char* curB = cur + QM * QK * 2;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[kk][i] = read_frag_q(cur, wm * 128 + i * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[kk][j] = read_frag_q(curB, wn * 64 + j * 32 + frow, kk * 2 + fk);
+    // unit of K-step (t + d) of the virtual stream (continues into the next tile) -> buffer X
+    enum { U_A0 = 0, U_B0 = 1, U_B1 = 2, U_A1 = 3 };
+    auto issue = [&](auto UT, auto XT, int t, int d) {
+        constexpr int U = decltype(UT)::value, X = decltype(XT)::value;
+        constexpr bool isA = (U == U_A0 || U == U_A1);
+        constexpr int h = (U == U_A1 || U == U_B1) ? 1 : 0;
+        const int kt = t + d;
+        const bool in_cur = kt < nt;
+        const unsigned kb = (unsigned)(in_cur ? kt : kt - nt) * 128u;
+        const unsigned base = isA ? (in_cur ? curA : nxtA) : (in_cur ? curB : nxtB);
+        const unsigned dst = lds_base + X * P::BUF + (isA ? P::off_a(h) : P::off_b(h));
+        if constexpr (isA) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, to_lds(dst + wave * 1024), 16, relA + (base + dA[h][0]), kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, to_lds(dst + pa1 * 1024), 16, relA + (base + dA[h][1]), kb, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, to_lds(dst + wave * 1024), 16, relB + (base + dB[h][0]), kb, 0, 0);
+            if (vb1[h])
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, to_lds(dst + pb1[h] * 1024), 16, relB + (base + dB[h][1]), kb, 0, 0);
         }
     };
-    auto compute_stage = [&]() {
-        if (prio) __builtin_amdgcn_s_setprio(1);
+    auto wait_dma = [&]() {  // everything but the newest K-step's worth of this wave's DMA has landed
+        if constexpr (P::W == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    };
+
+    f32x4v acc[P::MT][P::NT];
+#pragma unroll
+    for (int i = 0; i < P::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < P::NT; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    bf16x8 fa[P::QM * 2], fb[2][P::QN * 2];  // [tile * 2 + kk]; the A set of half 1 replaces half 0 in phase 2
+
+    auto read_a = [&](auto XT, auto QT) {
+        constexpr int X = decltype(XT)::value, qa = decltype(QT)::value;
+        read_frags<P::QM, P::off_a(qa)>(fa, a_addr0 + X * P::BUF, a_addr1 + X * P::BUF);
+    };
+    auto read_b = [&](auto XT, auto QT) {
+        constexpr int X = decltype(XT)::value, qb = decltype(QT)::value;
+        read_frags<P::QN, P::off_b(qb)>(fb[qb], b_addr0 + X * P::BUF, b_addr1 + X * P::BUF);
+    };
+    // accumulator quadrant (qa, qb) += A(qa) x B(qb) over the K-step; operands swapped: D[n][m]
+    auto mma = [&](auto QA, auto QB) {
+        constexpr int qa = decltype(QA)::value, qb = decltype(QB)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ZG_SB();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < P::QM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-        if (prio) __builtin_amdgcn_s_setprio(0);
-    };
-    // even barrier of stage s: wait for the stage, synchronise, refill the slot freed one stage ago
-    auto even_barrier = [&](int st) {
-        if (st < nt) {
-            const int ahead = min(nt - 1 - st, kQSlots - 2);  // stages issued beyond st (4 loads each)
-            if (ahead >= 3) __builtin_amdgcn_s_waitcnt(0x0f7c);       // vmcnt(12)
-            else if (ahead == 2) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
-            else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4)
-            else __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
-        }
-        __builtin_amdgcn_s_barrier();
-        const int nx = st + kQSlots - 1;  // its slot was last read one stage ago (group 1, interval 2 st - 1)
-        if (nx < nt) stage_q(A, B, K, ms, ns, nx * QK, lds + (nx % kQSlots) * kQStage, wave, lane);
-    };
-    // Both groups execute exactly 2 * nt + 1 barriers.
-    if (grp == 0) {
-        for (int st = 0; st < nt; ++st) {
-            even_barrier(st);                  // barrier 2*st
-            load_stage(st);                    // interval 2*st
-            __builtin_amdgcn_s_barrier();      // barrier 2*st + 1
-            compute_stage();                   // interval 2*st + 1
-        }
-        even_barrier(nt);                      // barrier 2*nt (group 1 is still computing after it)
-    } else {
-        even_barrier(0);                       // barrier 0, idle interval 0
-        for (int st = 0; st < nt; ++st) {
-            __builtin_amdgcn_s_barrier();      // barrier 2*st + 1
-            load_stage(st);                    // interval 2*st + 1
-            even_barrier(st + 1);              // barrier 2*st + 2
-            compute_stage();                   // interval 2*st + 2
-        }
-    }
-    __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
-
-    // epilogue in two halves of 64 rows per wave (16 KiB of staging per wave even for fp32 output)
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
-    constexpr int ROW_BYTES = 64 * ESZ, CHUNKS_PER_ROW = ROW_BYTES / 16, CHUNKS = 64 * CHUNKS_PER_ROW;
-    char* wtile = lds + wave * (64 * 64 * 4);
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bv[j] = bias ? bias[n0 + wn * 64 + j * 32 + frow] : 0.0f;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + frow;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    float v = acc[half * 2 + ii][j][r] + bv[j];
-                    if (GELU) v = gelu_fast(v);
-                    if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = f32_to_bf16_rne(v);
-                    else reinterpret_cast<float*>(wtile)[row * 64 + col] = v;
-                }
-        }
-#pragma unroll
-        for (int it = 0; it < CHUNKS / 64; ++it) {
-            const int c = it * 64 + lane;
-            const int row = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + row * ROW_BYTES + cc * 16);
-            char* dst = reinterpret_cast<char*>(C) +
-                        ((size_t)(m0 + wm * 128 + half * 64 + row) * ldc + n0 + wn * 64) * ESZ + cc * 16;
-            *reinterpret_cast<u32x4*>(dst) = v;
-        }
-    }
-}
-
-template <bool GELU, bool OUT_BF16>
-int launch_gemm_q_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                    hipStream_t s) {
-    static bool raised = false;
-    if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_q_kernel<GELU, OUT_BF16>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kQLds));
-        raised = true;
-    }
-    const int tiles_m = M / QM, tiles_n = N / QN;
-    static const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
-    int gw = gw_env > 0 ? gw_env : 6;
-    if (gw > tiles_n) gw = tiles_n;
-    hipLaunchKernelGGL((gemm_nt_bf16_q_kernel<GELU, OUT_BF16>), dim3(tiles_m * tiles_n), dim3(512), kQLds, s, A, B,
-                       bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n, gw, getenv("ZGPT2_PRIO") ? atoi(getenv("ZGPT2_PRIO")) : 1,
-                       getenv("ZGPT2_ABLATE") ? atoi(getenv("ZGPT2_ABLATE")) : 0);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// 256 x 256 tile, FULL-LINE staging.  The BK = 32 ring above asks L2 for every 128-B line twice (64 B per
-// row per stage) and tops out at ~14 B/clk/CU of LDS-DMA; the BK = 64 kernels move ~19 B/clk/CU.  Here a
-// ring unit is HALF the rows (128 of A + 128 of B) for 64 k: 32 pieces of 8 rows x 128 B, so each line is
-// requested once.  K-step T (64 k) consumes units 2T (row half 0) and 2T + 1 (row half 1); 5 slots of
-// 32 KiB; after barrier T the units 2T+3 and 2T+4 are issued into the slots step T-1 just released.
-template <bool GELU, bool OUT_BF16, int MF>  // MF = 32: v_mfma_f32_32x32x16_bf16, 16: v_mfma_f32_16x16x32_bf16
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_f_kernel(const bf16_t* __restrict__ A,
-                                                                const bf16_t* __restrict__ B,
-                                                                const float* __restrict__ bias, void* __restrict__ C,
-                                                                int M, int N, int K, int ldc, int tiles_n, int n_tiles,
-                                                                int gw, int ablate) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int bid = blockIdx.x;
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    int tm, tn;
-    {
-        const int tiles_m = n_tiles / tiles_n;
-        const int band = tile / (tiles_m * gw), full = tiles_n / gw;
-        if (band < full) {
-            const int r = tile - band * tiles_m * gw;
-            tm = r / gw;
-            tn = band * gw + r % gw;
-        } else {
-            const int w = tiles_n - full * gw, r = tile - full * tiles_m * gw;
-            tm = r / w;
-            tn = full * gw + r % w;
-        }
-    }
-    const int m0 = tm * QM, n0 = tn * QN;
-
-    typedef __attribute__((ext_vector_type(4))) float f32x4v;
-    f32x16 acc[4][2];     // MF == 32: 4 x 2 tiles of 32 x 32
-    f32x4v acc16[8][4];   // MF == 16: 8 x 4 tiles of 16 x 16
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-
-    const int nt = K / 64, nu = 2 * nt;
-    // unit u -> K-step u >> 1, row half u & 1; each wave issues 4 pieces (2 of A, 2 of B)
-    auto issue_unit = [&](int u) {
-        char* slot = lds + (u % 5) * 32768;
-        const int k0 = (u >> 1) * 64, half = u & 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int piece = wave * 4 + q;                 // 0..31: 16 A pieces then 16 B pieces, 8 rows each
-            const bool isB = piece >= 16;
-            const int prow = (isB ? piece - 16 : piece) * 8 + (lane >> 3);  // row inside the 128-row half
-            const int pos = lane & 7;
-            const int chunk = pos ^ ((prow >> 1) & 7);
-            const bf16_t* src = (isB ? B + (size_t)(n0 + half * 128 + prow) * K : A + (size_t)(m0 + half * 128 + prow) * K) +
-                                k0 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(slot + piece * 1024), 16, 0, 0);
-        }
-    };
-    issue_unit(0);
-    if (nu > 1) issue_unit(1);
-    if (nu > 2) issue_unit(2);
-
-    const int frow = lane & 31, fk = lane >> 5;
-    for (int T = 0; T < nt; ++T) {
-        if (T + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4): units 2T, 2T+1 landed; 2T+2 may fly
-        else __builtin_amdgcn_s_waitcnt(0x0f70);
-        __builtin_amdgcn_s_barrier();
-        if (2 * T + 3 < nu) issue_unit(2 * T + 3);
-        if (2 * T + 4 < nu) issue_unit(2 * T + 4);
-        const char* ua = lds + ((2 * T + wm) % 5) * 32768;                 // A half wm
-        const char* ub = lds + ((2 * T + (wn >> 1)) % 5) * 32768 + 16384;  // B half wn >> 1
-        __builtin_amdgcn_s_setprio(1);
-        if constexpr (MF == 16) {
-            const int r16 = lane & 15, q16 = lane >> 4;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {  // two 32-k substeps per unit pair
-                bf16x8 a[8], b[4];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = read_frag(ua, i * 16 + r16, kk * 4 + q16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = read_frag(ub, (wn & 1) * 64 + j * 16 + r16, kk * 4 + q16);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc16[i][j], 0, 0, 0);
-            }
-        } else
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[4], b[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = read_frag(ua, i * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = read_frag(ub, (wn & 1) * 64 + j * 32 + frow, kk * 2 + fk);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < P::QN; ++j)
+                    acc[qa * P::QM + i][qb * P::QN + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        fb[qb][j * 2 + kk], fa[i * 2 + kk], acc[qa * P::QM + i][qb * P::QN + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-    }
-    __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
-    if (ablate & 32) {  // diagnostic: no epilogue at all (keep the accumulators alive)
-        float t = 0.0f;
-        for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) t += acc16[i][j][0];
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) t += acc[i][j][0];
-        if (t == 1.2345f) reinterpret_cast<float*>(C)[0] = t;
-        return;
-    }
+        ZG_SB();
+    };
+    auto bar = [&]() {
+        ZG_SB();
+        __builtin_amdgcn_s_barrier();
+        ZG_SB();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
 
+    // one K-step (index t of the current tile) out of buffer X; units of steps t + 1 / t + 2 are issued on the way
+    auto kstep = [&](auto XT, int t) {
+        constexpr int X = decltype(XT)::value;
+        using XO = std::integral_constant<int, X ^ 1>;
+        // phase 0: quadrant (0, 0)
+        read_b(XT, I0{});
+        read_a(XT, I0{});
+        issue(I2{}, XO{}, t, 1);  // B half 1 of step t + 1
+        wait_dma();               // B half 1 of step t landed (read in phase 1)
+        bar();
+        mma(I0{}, I0{});
+        bar();
+        // phase 1: quadrant (0, 1)
+        read_b(XT, I1{});
+        issue(I3{}, XO{}, t, 1);  // A half 1 of step t + 1
+        wait_dma();               // A half 1 of step t landed (read in phase 2)
+        bar();
+        mma(I0{}, I1{});
+        bar();
+        // phase 2: quadrant (1, 1)
+        read_a(XT, I1{});
+        issue(I0{}, XT, t, 2);    // A half 0 of step t + 2 (this buffer: last read two phases ago)
+        bar();
+        mma(I1{}, I1{});
+        bar();
+        // phase 3: quadrant (1, 0), no fragment reads
+        issue(I1{}, XT, t, 2);    // B half 0 of step t + 2
+        wait_dma();               // A half 0 / B half 0 of step t + 1 landed (read in the next phase 0)
+        bar();
+        mma(I1{}, I0{});
+        bar();
+    };
+
+    // ---- epilogue of one tile: bias (+ GELU), convert, wave-private LDS staging, full-row 16-B stores
     constexpr int ESZ = OUT_BF16 ? 2 : 4;
-    constexpr int ROW_BYTES = 64 * ESZ, CHUNKS_PER_ROW = ROW_BYTES / 16, CHUNKS = 64 * CHUNKS_PER_ROW;
-    char* wtile = lds + wave * (64 * 64 * 4);
-    float bv[2];
+    constexpr int NPASS = OUT_BF16 ? 1 : 2;       // fp32 output goes in two column halves through the same staging rows
+    constexpr int NTP = P::NT / NPASS;            // n-tiles per pass
+    constexpr int CPR = P::TN * 2 / 16;           // 16-B chunks per staged row
+    auto epilogue = [&]() {
+        int lane_e = lane;  // opaque copy: nothing derived from it can be hoisted into (and pinned across) the main loop
+        asm volatile("" : "+v"(lane_e));
+        const int l15 = lane_e & 15, lq = lane_e >> 4;
+        char* st = lds + P::ST_OFF + wave * P::ST_WAVE;
+        f32x4v bv[P::NT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bv[j] = bias ? bias[n0 + wn * 64 + j * 32 + frow] : 0.0f;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + frow;
-            if constexpr (MF == 32) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                        float v = acc[half * 2 + ii][j][r] + bv[j];
-                        if (GELU) v = gelu_fast(v);
-                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + col] = cvt_bf16(v);
-                        else reinterpret_cast<float*>(wtile)[row * 64 + col] = v;
-                    }
-            }
-        }
-        if constexpr (MF == 16) {  // D: col = lane & 15, row = 4 (lane >> 4) + r
-            const int c16 = lane & 15, q16 = lane >> 4;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float b16 = bias ? bias[n0 + wn * 64 + jj * 16 + c16] : 0.0f;
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = ii * 16 + q16 * 4 + r;
-                        float v = acc16[half * 4 + ii][jj][r] + b16;
-                        if (GELU) v = gelu_fast(v);
-                        if (OUT_BF16) reinterpret_cast<bf16_t*>(wtile)[row * 64 + jj * 16 + c16] = cvt_bf16(v);
-                        else reinterpret_cast<float*>(wtile)[row * 64 + jj * 16 + c16] = v;
-                    }
-            }
+        for (int j = 0; j < P::NT; ++j) {
+            const int col = n0 + wc * P::TN + j * 16 + 4 * lq;
+            bv[j] = (bias != nullptr && col < N) ? *reinterpret_cast<const f32x4v*>(bias + col) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
-        for (int it = 0; it < CHUNKS / 64; ++it) {
-            const int c = it * 64 + lane;
-            const int row = c / CHUNKS_PER_ROW, cc = c % CHUNKS_PER_ROW;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + row * ROW_BYTES + cc * 16);
-            char* dst = reinterpret_cast<char*>(C) +
-                        ((size_t)(m0 + wm * 128 + half * 64 + row) * ldc + n0 + wn * 64) * ESZ + cc * 16;
-            if (!(ablate & 16)) *reinterpret_cast<u32x4*>(dst) = v;
-            else if (v.x == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = v;
+        for (int i = 0; i < P::MT; ++i) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+                for (int jj = 0; jj < NTP; ++jj) {
+                    const int j = ps * NTP + jj;
+                    f32x4v v = acc[i][j] + bv[j];
+                    if (GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+                    }
+                    if (OUT_BF16) {
+                        u32x2 pk;
+                        pk.x = cvt_pk_bf16(v[0], v[1]);
+                        pk.y = cvt_pk_bf16(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>(st + l15 * P::ST_ROW + (jj * 16 + 4 * lq) * 2) = pk;
+                    } else {
+                        *reinterpret_cast<f32x4v*>(st + l15 * P::ST_ROW + (jj * 16 + 4 * lq) * 4) = v;
+                    }
+                }
+                // 16 rows x (TN * 2) bytes back out as whole rows
+#pragma unroll
+                for (int it = 0; it < (16 * CPR) / 64; ++it) {
+                    const int c = it * 64 + lane_e, row = c / CPR, ch = c % CPR;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * P::ST_ROW + ch * 16);
+                    const int grow = m0 + wr * P::TM + i * 16 + row;
+                    const int gcol = n0 + wc * P::TN + ps * (P::TN / NPASS) + ch * (16 / ESZ);
+                    if (grow < M && gcol < N)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(C) + ((size_t)grow * ldc + gcol) * ESZ) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < P::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < P::NT; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        // stores and DMA share the vmcnt counter and retire out of order with respect to each other: drain
+        // before the main loop relies on counted waits again (the prefetched units landed long ago)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ZG_SB();
+    };
+    auto next_tile = [&]() {
+        idx = nidx;
+        m0 = ntm * 256;
+        n0 = ntn * BN;
+        curA = nxtA;
+        curB = nxtB;
+        nidx = idx + gx;
+        nxtA = kOob;
+        nxtB = kOob;
+        if (nidx < t_end) {
+            tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
+            nxtA = (unsigned)ntm * 256u * (unsigned)K * 2u;
+            nxtB = (unsigned)ntn * BN * (unsigned)K * 2u;
+        }
+    };
+
+    // ---- prologue: K-step 0 complete + the first two units of K-step 1, as the steady state expects
+    issue(I0{}, I0{}, 0, 0);
+    issue(I1{}, I0{}, 0, 0);
+    issue(I2{}, I0{}, 0, 0);
+    issue(I3{}, I0{}, 0, 0);
+    issue(I0{}, I1{}, 0, 1);
+    issue(I1{}, I1{}, 0, 1);
+    wait_dma();  // A half 0 / B half 0 of step 0
+    bar();
+    if (grp == 1) bar();  // stagger: group 1 runs one barrier behind group 0
+
+    // two K-steps per trip so that the buffer is a compile-time constant; a tile may end after either
+    int t = 0;
+    for (;;) {
+        kstep(I0{}, t);
+        if (++t == nt) {
+            epilogue();
+            if (idx + gx >= t_end) break;
+            next_tile();
+            t = 0;
+        }
+        kstep(I1{}, t);
+        if (++t == nt) {
+            epilogue();
+            if (idx + gx >= t_end) break;
+            next_tile();
+            t = 0;
         }
     }
+    if (grp == 0) bar();
 }
 
-template <bool GELU, bool OUT_BF16, int MF>
-int launch_gemm_f_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                    hipStream_t s) {
+template <int BN, bool GELU, bool OUT_BF16>
+int launch_p8(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, hipStream_t s) {
+    using P = P8<BN>;
     static bool raised = false;
     if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_f_kernel<GELU, OUT_BF16, MF>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<BN, GELU, OUT_BF16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
         raised = true;
     }
-    const int tiles_m = M / QM, tiles_n = N / QN;
-    static const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
-    int gw = gw_env > 0 ? gw_env : 6;
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
+    const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
+    int gw = gw_env > 0 ? gw_env : 8;
     if (gw > tiles_n) gw = tiles_n;
-    hipLaunchKernelGGL((gemm_nt_bf16_f_kernel<GELU, OUT_BF16, MF>), dim3(tiles_m * tiles_n), dim3(512), 5 * 32768, s, A, B,
-                       bias, C, M, N, K, ldc, tiles_n, tiles_m * tiles_n, gw,
-                       getenv("ZGPT2_ABLATE") ? atoi(getenv("ZGPT2_ABLATE")) : 0);
+    const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;  // tests: few workgroups, many tiles each
+    const int cus = cus_env > 0 ? cus_env : 256;
+    const int grid = n_tiles < cus ? n_tiles : cus;
+    hipLaunchKernelGGL((gemm_p8_kernel<BN, GELU, OUT_BF16>), dim3(grid), dim3(512), P::LDS, s, A, B, bias, C, M, N, K,
+                       ldc, tiles_m, tiles_n, gw);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
+}
+
+template <int BN>
+int launch_p8_bn(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, bool gelu,
+                 bool out_bf16, hipStream_t s) {
+    if (gelu) return out_bf16 ? launch_p8<BN, true, true>(A, B, bias, C, M, N, K, ldc, s)
+                              : launch_p8<BN, true, false>(A, B, bias, C, M, N, K, ldc, s);
+    return out_bf16 ? launch_p8<BN, false, true>(A, B, bias, C, M, N, K, ldc, s)
+                    : launch_p8<BN, false, false>(A, B, bias, C, M, N, K, ldc, s);
 }
 
 }  // namespace
 
 int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
                         bool gelu, bool out_bf16, hipStream_t s) {
-    ZG_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0, ZG_ERR_UNSUPPORTED,
-               "gemm_bf16_nt: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, BM, BN, BK);
-    ZG_REQUIRE(ldc >= N && ldc % 8 == 0, ZG_ERR_ARG, "gemm_bf16_nt: ldc %d", ldc);
-    static const int variant = getenv("ZGPT2_GEMM") ? atoi(getenv("ZGPT2_GEMM")) : 0;  // 1: force 128x128
-    if (M % QM == 0 && N % QN == 0 && K % 64 == 0 && (variant == 0 || variant == 5)) {
-        if (gelu) return out_bf16 ? launch_gemm_f_t<true, true, 16>(A, B, bias, C, M, N, K, ldc, s)
-                                  : launch_gemm_f_t<true, false, 16>(A, B, bias, C, M, N, K, ldc, s);
-        return out_bf16 ? launch_gemm_f_t<false, true, 16>(A, B, bias, C, M, N, K, ldc, s)
-                        : launch_gemm_f_t<false, false, 16>(A, B, bias, C, M, N, K, ldc, s);
-    }
-    if (M % QM == 0 && N % QN == 0 && K % 64 == 0 && variant == 4) {
-        if (gelu) return out_bf16 ? launch_gemm_f_t<true, true, 32>(A, B, bias, C, M, N, K, ldc, s)
-                                  : launch_gemm_f_t<true, false, 32>(A, B, bias, C, M, N, K, ldc, s);
-        return out_bf16 ? launch_gemm_f_t<false, true, 32>(A, B, bias, C, M, N, K, ldc, s)
-                        : launch_gemm_f_t<false, false, 32>(A, B, bias, C, M, N, K, ldc, s);
-    }
-    if (M % QM == 0 && N % QN == 0 && variant == 3) {
-        if (gelu) return out_bf16 ? launch_gemm_q_t<true, true>(A, B, bias, C, M, N, K, ldc, s)
-                                  : launch_gemm_q_t<true, false>(A, B, bias, C, M, N, K, ldc, s);
-        return out_bf16 ? launch_gemm_q_t<false, true>(A, B, bias, C, M, N, K, ldc, s)
-                        : launch_gemm_q_t<false, false>(A, B, bias, C, M, N, K, ldc, s);
-    }
-    if (M % DM == 0 && variant != 1) {
-        if (gelu) return out_bf16 ? launch_gemm_deep_t<true, true>(A, B, bias, C, M, N, K, ldc, s)
-                                  : launch_gemm_deep_t<true, false>(A, B, bias, C, M, N, K, ldc, s);
-        return out_bf16 ? launch_gemm_deep_t<false, true>(A, B, bias, C, M, N, K, ldc, s)
-                        : launch_gemm_deep_t<false, false>(A, B, bias, C, M, N, K, ldc, s);
-    }
-    if (gelu) return out_bf16 ? launch_gemm_t<true, true>(A, B, bias, C, M, N, K, ldc, s)
-                              : launch_gemm_t<true, false>(A, B, bias, C, M, N, K, ldc, s);
-    return out_bf16 ? launch_gemm_t<false, true>(A, B, bias, C, M, N, K, ldc, s)
-                    : launch_gemm_t<false, false>(A, B, bias, C, M, N, K, ldc, s);
+    ZG_REQUIRE(M > 0 && N > 0 && K >= 64 && K % 64 == 0, ZG_ERR_UNSUPPORTED,
+               "gemm_bf16_nt: M=%d N=%d K=%d: K must be a positive multiple of 64", M, N, K);
+    ZG_REQUIRE(N % 8 == 0 && ldc >= N && ldc % 8 == 0, ZG_ERR_UNSUPPORTED, "gemm_bf16_nt: N=%d ldc=%d must be multiples of 8", N, ldc);
+    ZG_REQUIRE((size_t)M * K < (1u << 30) && (size_t)N * K < (1u << 30), ZG_ERR_SHAPE, "gemm_bf16_nt: operand over 2 GiB");
+    // tile width: the one that wastes fewer CU-rounds (M = 8192, N = 3072: 512 tiles of 256 x 192 = 2.0 per CU
+    // against 384 tiles of 256 x 256 = two rounds with half the chip idle in the second)
+    const int bn_env = getenv("ZGPT2_GEMM_BN") ? atoi(getenv("ZGPT2_GEMM_BN")) : 0;
+    auto cost = [&](int bn) {
+        const long tiles = (long)((M + 255) / 256) * ((N + bn - 1) / bn);
+        return ((tiles + 255) / 256) * bn;
+    };
+    int bn = cost(192) < cost(256) ? 192 : 256;
+    if (bn_env == 192 || bn_env == 256) bn = bn_env;
+    return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, K, ldc, gelu, out_bf16, s)
+                     : launch_p8_bn<256>(A, B, bias, C, M, N, K, ldc, gelu, out_bf16, s);
 }
 
 }  // namespace zg
