@@ -45,6 +45,24 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
 }
 
+// Two elements at a time: the multiplies / FMAs become v_pk_*_f32 (the epilogue is VALU bound: ~1000 issue slots
+// per wave per tile against ~25 free slots per phase in the main loop).
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+__device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
+    const f32x2v t = x * x;
+    const f32x2v p = __builtin_elementwise_fma(t, f32x2v{k2, k2}, f32x2v{k1, k1});
+    const f32x2v arg = x * p;
+    f32x2v e;
+    e.x = __builtin_amdgcn_exp2f(arg.x);
+    e.y = __builtin_amdgcn_exp2f(arg.y);
+    const f32x2v d = e + f32x2v{1.0f, 1.0f};
+    f32x2v r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;
+}
+
 template <int BN_>
 struct P8 {
     static constexpr int BM = 256, BN = BN_, BK = 64;
@@ -76,6 +94,24 @@ __device__ __forceinline__ void read_frags(bf16x8 (&f)[NTILE * 2], unsigned addr
     }
 }
 
+// hand-issued 16-B load (scalar base + per-lane byte offset) and the matching counted wait that hands the
+// destination registers back to the compiler
+__device__ __forceinline__ void load_x4(f32x4v& dst, unsigned byte_off, const float* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base));
+}
+template <int CNT, int N>
+__device__ __forceinline__ void wait_loads(f32x4v (&v)[N]) {
+    static_assert(N == 4 || N == 6, "wait_loads: 4 or 6 destination vectors");
+    static_assert(CNT == 7 || CNT == 8, "wait_loads: count");
+    if constexpr (N == 4) {
+        if constexpr (CNT == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+        else asm volatile("s_waitcnt vmcnt(7)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    } else {
+        if constexpr (CNT == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+        else asm volatile("s_waitcnt vmcnt(7)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+    }
+}
+
 #define ZG_SB() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ lds_ptr_t to_lds(unsigned byte_addr) { return (lds_ptr_t)(size_t)byte_addr; }
 
@@ -97,7 +133,7 @@ __device__ __forceinline__ void tile_of(int idx, int tiles_m, int tiles_n, int g
 template <int BN, bool GELU, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, void* __restrict__ C, int M,
-                                                         int N, int K, int ldc, int tiles_m, int tiles_n, int gw) {
+                                                         int N, int K, int ldc, int tiles_m, int tiles_n, int gw, int dbg) {
     using P = P8<BN>;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -196,11 +232,27 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
         else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     };
 
+    // The accumulators START at the bias, as the reference pre-fills the output rows with the bias and accumulates
+    // with beta = 1 (src/ops.zig:24-29, :42): no bias add (and no zeroing) in the epilogue.
     f32x4v acc[P::MT][P::NT];
+    auto load_bias = [&](f32x4v (&bv)[P::NT], int n0_) {
 #pragma unroll
-    for (int i = 0; i < P::MT; ++i)
+        for (int j = 0; j < P::NT; ++j) {
+            const int col = n0_ + wc * P::TN + j * 16 + 4 * (lane >> 4);
+            bv[j] = (bias != nullptr && col < N) ? *reinterpret_cast<const f32x4v*>(bias + col) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto init_acc = [&](const f32x4v (&bv)[P::NT]) {
 #pragma unroll
-        for (int j = 0; j < P::NT; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < P::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < P::NT; ++j) acc[i][j] = bv[j];
+    };
+    {
+        f32x4v bv0[P::NT];
+        load_bias(bv0, n0);
+        init_acc(bv0);
+    }
     bf16x8 fa[P::QM * 2], fb[2][P::QN * 2];  // [tile * 2 + kk]; the A set of half 1 replaces half 0 in phase 2
 
     auto read_a = [&](auto XT, auto QT) {
@@ -239,15 +291,36 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
     using I3 = std::integral_constant<int, 3>;
 
     // one K-step (index t of the current tile) out of buffer X; units of steps t + 1 / t + 2 are issued on the way
+    // The next tile's bias (its accumulators start there) is fetched during the current tile's last K-step by
+    // hand-issued loads: a compiler-tracked load consumed after the epilogue's stores would be waited for with
+    // vmcnt(0), i.e. would drain the stores.  Loads retire in order among themselves, and exactly W DMA pieces
+    // follow these, so the epilogue's leading vmcnt(W) covers them.
+    f32x4v bvn[P::NT];
+    auto prefetch_bias = [&]() {
+        if (bias == nullptr) return;
+        const int nn0 = (idx + gx < t_end) ? ntn * BN : n0;
+#pragma unroll
+        for (int j = 0; j < P::NT; ++j) {
+            int col = nn0 + wc * P::TN + j * 16 + 4 * (lane >> 4);
+            col = min(col, N - 4);  // columns past N are masked at the store; keep the address valid
+            load_x4(bvn[j], (unsigned)col * 4u, bias);
+        }
+    };
+    bool owe = false;  // group 1 owes the barrier that puts it one interval behind group 0 again (after a tile end)
     auto kstep = [&](auto XT, int t) {
         constexpr int X = decltype(XT)::value;
         using XO = std::integral_constant<int, X ^ 1>;
         // phase 0: quadrant (0, 0)
         read_b(XT, I0{});
         read_a(XT, I0{});
+        if (t == nt - 1) prefetch_bias();  // exactly W DMA pieces are issued between here and the epilogue
         issue(I2{}, XO{}, t, 1);  // B half 1 of step t + 1
         wait_dma();               // B half 1 of step t landed (read in phase 1)
         bar();
+        if (owe) {
+            bar();
+            owe = false;
+        }
         mma(I0{}, I0{});
         bar();
         // phase 1: quadrant (0, 1)
@@ -268,7 +341,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
         wait_dma();               // A half 0 / B half 0 of step t + 1 landed (read in the next phase 0)
         bar();
         mma(I1{}, I0{});
-        bar();
+        // Tile end: group 1 goes straight from its last MFMAs into its epilogue (no barrier), so that the two
+        // groups' epilogues — VALU bound, with a store tail — run side by side instead of one after the other.
+        if (grp == 1 && t == nt - 1) owe = true;
+        else bar();
     };
 
     // ---- epilogue of one tile: bias (+ GELU), convert, wave-private LDS staging, full-row 16-B stores
@@ -277,15 +353,26 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
     constexpr int NTP = P::NT / NPASS;            // n-tiles per pass
     constexpr int CPR = P::TN * 2 / 16;           // 16-B chunks per staged row
     auto epilogue = [&]() {
+        if (dbg & 4) {  // diagnostic: no epilogue at all (accumulators kept alive through an impossible store)
+            float tsum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < P::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < P::NT; ++j) {
+                    tsum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+                    acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};  // (diagnostic path: bias dropped)
+                }
+            if (tsum == 1.2345e33f) reinterpret_cast<float*>(C)[0] = tsum;
+            return;
+        }
         int lane_e = lane;  // opaque copy: nothing derived from it can be hoisted into (and pinned across) the main loop
         asm volatile("" : "+v"(lane_e));
         const int l15 = lane_e & 15, lq = lane_e >> 4;
         char* st = lds + P::ST_OFF + wave * P::ST_WAVE;
-        f32x4v bv[P::NT];
+        if (bias != nullptr) wait_loads<P::W>(bvn);
+        else {
 #pragma unroll
-        for (int j = 0; j < P::NT; ++j) {
-            const int col = n0 + wc * P::TN + j * 16 + 4 * lq;
-            bv[j] = (bias != nullptr && col < N) ? *reinterpret_cast<const f32x4v*>(bias + col) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < P::NT; ++j) bvn[j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int i = 0; i < P::MT; ++i) {
@@ -294,10 +381,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int jj = 0; jj < NTP; ++jj) {
                     const int j = ps * NTP + jj;
-                    f32x4v v = acc[i][j] + bv[j];
+                    f32x4v v = acc[i][j];
                     if (GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+                        const f32x2v g0 = gelu_fast2(f32x2v{v[0], v[1]}), g1 = gelu_fast2(f32x2v{v[2], v[3]});
+                        v = f32x4v{g0.x, g0.y, g1.x, g1.y};
                     }
                     if (OUT_BF16) {
                         u32x2 pk;
@@ -315,18 +402,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
                     const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * P::ST_ROW + ch * 16);
                     const int grow = m0 + wr * P::TM + i * 16 + row;
                     const int gcol = n0 + wc * P::TN + ps * (P::TN / NPASS) + ch * (16 / ESZ);
-                    if (grow < M && gcol < N)
+                    if (grow < M && gcol < N && (!(dbg & 1) || v.x == 0x12345678u))
                         *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(C) + ((size_t)grow * ldc + gcol) * ESZ) = v;
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < P::MT; ++i)
-#pragma unroll
-            for (int j = 0; j < P::NT; ++j) acc[i][j] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-        // stores and DMA share the vmcnt counter and retire out of order with respect to each other: drain
-        // before the main loop relies on counted waits again (the prefetched units landed long ago)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        init_acc(bvn);
+        // The stores share the vmcnt counter with the DMA and may retire out of order with respect to it.  The
+        // counted waits stay SAFE without a drain: the DMA pieces retire in order among themselves, so "at most W
+        // operations outstanding" still implies "at most the W newest DMA pieces outstanding" — stores still in
+        // flight only make a wait conservative.  (dbg bit 8: drain anyway, for A/B timing.)
+        if (dbg & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ZG_SB();
     };
     auto next_tile = [&]() {
@@ -374,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
             t = 0;
         }
     }
-    if (grp == 0) bar();
+    bar();  // group 0: the barrier group 1 ran ahead by at start-up; group 1: the one it still owes
 }
 
 template <int BN, bool GELU, bool OUT_BF16>
@@ -394,7 +480,7 @@ int launch_p8(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int 
     const int cus = cus_env > 0 ? cus_env : 256;
     const int grid = n_tiles < cus ? n_tiles : cus;
     hipLaunchKernelGGL((gemm_p8_kernel<BN, GELU, OUT_BF16>), dim3(grid), dim3(512), P::LDS, s, A, B, bias, C, M, N, K,
-                       ldc, tiles_m, tiles_n, gw);
+                       ldc, tiles_m, tiles_n, gw, getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
