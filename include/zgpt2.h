@@ -53,10 +53,16 @@ const char* zg_last_error(void);
  * own stream. */
 int zg_set_stream(void* hip_stream);
 int zg_synchronize(void);
-/* Upload a host tensor once and keep a device mirror keyed by its host address: later op-tier
- * calls that receive the same host pointer use the mirror instead of re-staging it (weights are
- * borrowed for the life of the arena in the reference, src/main.zig:349-351). */
+/* Upload a host PARAMETER tensor (Linear / Embedding weight, bias, LayerNorm vectors) once and keep a
+ * device mirror keyed by its host address: later op-tier calls that receive the same host pointer WITH THE
+ * SAME LENGTH in a parameter position use the mirror instead of re-staging it (weights are borrowed for
+ * the life of the arena in the reference, src/main.zig:349-351).  Activation arguments (inputs, idxs,
+ * q / k / v) are never looked up, so a freed weight's address may be reused for them.  Re-registering an
+ * address replaces its mirror; host weights changed in place after registration must be registered
+ * again.  zg_unregister_tensor drops one mirror (the `defer allocator.free(weight)` moment of
+ * src/tests.zig). */
 int zg_register_tensor(const float* host_ptr, size_t len);
+int zg_unregister_tensor(const float* host_ptr);
 int zg_unregister_all(void);
 
 /* ------------------------------------------------------------------ op tier: src/ops.zig --- */
@@ -118,10 +124,15 @@ int zg_softmax(float* inputs, size_t inputs_len);
  * optional fused GELU — the same contraction as Linear.forward's cblas_sgemm(NoTrans, Trans)
  * (src/ops.zig:30-45) for large batch (prefill), with both operands in ops.Linear's K-contiguous
  * layouts.  A, B are bf16 bit patterns and C is bf16 (out_bf16 != 0) or fp32, all DEVICE pointers;
- * M, N multiples of 128, K multiple of 64.  Asynchronous on the library stream.
+ * any M, N a multiple of 8 (bf16 C) or 4 (fp32 C), K a multiple of 64 and at least 128.  Asynchronous on
+ * the library stream.  zg_linear_forward itself takes this path for batch >= 16 (fp32 operands split
+ * exactly into bf16 planes, so the result stays fp32-sgemm grade).
  * zg_f32_to_bf16 converts a device or host fp32 array into a device bf16 array (round to nearest even). */
 int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_null, void* C, size_t M,
                     size_t N, size_t K, int gelu, int out_bf16);
+/* Diagnostic: number of matrix-core GEMM launches so far in this process (tests assert which path a
+ * Linear took; no reference counterpart). */
+unsigned long long zg_debug_gemm_launches(void);
 int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len);
 
 /* ------------------------------------------------------------------ model tier: src/main.zig */

@@ -41,6 +41,11 @@ struct Linear {
         if (bias.ptr) check(zg_register_tensor(bias.ptr, bias.len));
         return Linear{in_features, out_features, weight, bias};
     }
+    // the reference frees borrowed weights with `defer allocator.free` (src/tests.zig); the mirror goes with them
+    void deinit() const {
+        zg_unregister_tensor(weight.ptr);
+        if (bias.ptr) zg_unregister_tensor(bias.ptr);
+    }
     void forward(Slice<const float> inputs, Slice<float> outputs) const {
         check(zg_linear_forward(in_features, out_features, weight.ptr, bias.ptr, inputs.ptr, inputs.len, outputs.ptr,
                                 outputs.len));
@@ -55,6 +60,7 @@ struct Embedding {
         check(zg_register_tensor(weight.ptr, weight.len));
         return Embedding{emb_dim, weight};
     }
+    void deinit() const { zg_unregister_tensor(weight.ptr); }
     void forward(Slice<const size_t> idxs, Slice<float> embeddings) const {
         check(zg_embedding_forward(emb_dim, weight.ptr, weight.len, idxs.ptr, idxs.len, embeddings.ptr, embeddings.len));
     }
@@ -73,6 +79,10 @@ struct LayerNorm {
         l.weight = weight;
         l.bias = bias;
         return l;
+    }
+    void deinit() const {
+        zg_unregister_tensor(weight.ptr);
+        zg_unregister_tensor(bias.ptr);
     }
     void forward(Slice<float> inputs) const {
         check(zg_layernorm_forward(n_features, weight.ptr, bias.ptr, eps, inputs.ptr, inputs.len));

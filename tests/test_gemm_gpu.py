@@ -22,14 +22,16 @@ def run_gemm(zg, a, b, bias, gelu, out_bf16):
     ad = torch.from_numpy(synth.to_bf16_bits(a).view(np.int16).reshape(m, k)).cuda()
     bd = torch.from_numpy(synth.to_bf16_bits(b).view(np.int16).reshape(n, k)).cuda()
     biasd = None if bias is None else torch.from_numpy(bias).cuda()
-    cd = torch.zeros((m, n), dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+    cd = torch.full((m, n), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the library launches on its own non-blocking stream
     _lib.check(zg.zg_gemm_bf16_nt(ad.data_ptr(), bd.data_ptr(), None if biasd is None else biasd.data_ptr(),
                                   cd.data_ptr(), m, n, k, int(gelu), int(out_bf16)))
     _lib.check(zg.zg_synchronize())
     return cd.float().cpu().numpy()
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (128, 256, 768), (256, 3072, 768), (384, 128, 3072), (1024, 768, 768)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 128), (128, 256, 768), (256, 3072, 768), (384, 128, 3072), (1024, 768, 768),
+                                   (100, 136, 192), (1000, 200, 128), (1023, 2304, 768), (16, 8, 1600)])
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gemm_matches_oracle_linear(zg, m, n, k, gelu):
     a = synth.fill_normal(1000 + m, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
@@ -53,7 +55,7 @@ def test_gemm_asymmetric_identity_detects_transposes(zg):
 
 
 def test_gemm_bf16_output_rounds_to_nearest(zg):
-    m, n, k = 128, 128, 192
+    m, n, k = 128, 136, 192
     a = synth.fill_normal(5, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
     b = synth.fill_normal(6, n * k, 0.0, 0.1, bf16=True).reshape(n, k)
     f32 = run_gemm(zg, a, b, None, False, out_bf16=False)
@@ -66,6 +68,42 @@ def test_gemm_rejects_unsupported_shapes(zg):
 
     t = torch.zeros(128 * 128, dtype=torch.int16, device="cuda")
     c = torch.zeros(128 * 128, dtype=torch.float32, device="cuda")
-    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 100, 128, 64, 0, 0) == -5
-    h = np.zeros(128 * 64, np.uint16)
-    assert zg.zg_gemm_bf16_nt(h.ctypes.data, t.data_ptr(), None, c.data_ptr(), 128, 128, 64, 0, 0) == -6
+    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 128, 64, 0, 0) == -5   # K < 128
+    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 128, 100, 0, 0) == -5  # K % 64
+    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 126, 128, 0, 0) == -5  # N % 4
+    h = np.zeros(128 * 128, np.uint16)
+    assert zg.zg_gemm_bf16_nt(h.ctypes.data, t.data_ptr(), None, c.data_ptr(), 128, 128, 128, 0, 0) == -6
+
+
+@pytest.mark.parametrize("bn,wgs", [(192, 8), (256, 8), (192, 3), (256, 5)])
+def test_gemm_many_tiles_per_workgroup(zg, bn, wgs, monkeypatch):
+    """The persistent kernel with few workgroups: every workgroup walks several tiles (tile hand-over with the
+    next tile's operands already in flight, odd K-step counts, ragged edges), both tile widths; repeated runs
+    must agree bit for bit (race screen)."""
+    monkeypatch.setenv("ZGPT2_GEMM_BN", str(bn))
+    monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
+    m, n, k = 1100, 776, 320
+    a = synth.fill_normal(7, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
+    b = synth.fill_normal(8, n * k, 0.0, 0.05, bf16=True).reshape(n, k)
+    bias = synth.fill_normal(9, n, 0.0, 0.5)
+    exp = oracle.gelu(oracle.linear_forward(k, n, b, bias, a))
+    runs = [run_gemm(zg, a, b, bias, True, out_bf16=False) for _ in range(3)]
+    assert_ref_close(exp, runs[0], f"gemm bn={bn} wgs={wgs}", scale_floor=4e-6)
+    assert all(np.array_equal(runs[0], r) for r in runs[1:])
+
+
+def test_gemm_768x3072_full_size_properties(zg):
+    """BASELINE's GEMM point at full size (M = 8192: 512 tiles, two per workgroup): linearity in A (rows scaled by
+    powers of two scale the pre-activation exactly) and agreement of a row sample with the oracle."""
+    import torch
+
+    m, n, k = 8192, 3072, 768
+    a = synth.fill_normal(11, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
+    b = synth.fill_normal(12, n * k, 0.0, 0.02, bf16=True).reshape(n, k)
+    bias = synth.fill_normal(13, n, 0.0, 0.02)
+    y = run_gemm(zg, a, b, bias, False, out_bf16=False)
+    y2 = run_gemm(zg, 2.0 * a, b, None, False, out_bf16=False)
+    y0 = run_gemm(zg, a, b, None, False, out_bf16=False)
+    assert np.array_equal(y2, 2.0 * y0)
+    rows = np.arange(0, m, 257)
+    assert_ref_close(oracle.linear_forward(k, n, b, bias, a[rows]), y[rows], "gemm 8192 row sample", scale_floor=4e-6)

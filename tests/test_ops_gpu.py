@@ -109,6 +109,50 @@ def test_linear_sweep(zg, m, k, n):
     assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n}", scale_floor=2e-6)
 
 
+@pytest.mark.parametrize("m,k,n", [(1024, 768, 3072), (16, 128, 8), (300, 3072, 768), (1023, 768, 2304), (64, 1600, 6400)])
+def test_linear_large_batch_runs_on_the_matrix_cores(zg, m, k, n):
+    """Linear.forward with batch >= 16 (ops.zig:22: batch = inputs.len / in_features) takes the MFMA GEMM — fp32
+    operands split exactly into bf16 planes — and still meets the reference tolerance against the fp32 oracle."""
+    w = synth.fill_normal(100 + n, n * k, 0, 0.05).reshape(n, k)
+    b = synth.fill_normal(200 + n, n, 0, 0.05)
+    x = synth.fill_normal(300 + m, m * k, 0, 1.0).reshape(m, k)
+    y = z(m, n)
+    before = zg.zg_debug_gemm_launches()
+    ops.Linear(k, n, w, b).forward(x, y)
+    assert zg.zg_debug_gemm_launches() == before + 1, "batch >= 16 Linear did not take the MFMA path"
+    assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n} (MFMA)", scale_floor=2e-6)
+    # batch < 16 stays on the GEMV kernels
+    before = zg.zg_debug_gemm_launches()
+    y8 = z(8, n)
+    ops.Linear(k, n, w, b).forward(x[:8], y8)
+    assert zg.zg_debug_gemm_launches() == before
+    assert_ref_close(y[:8], y8, "GEMV path vs MFMA path", scale_floor=2e-6)
+
+
+def test_registered_mirror_is_never_used_for_activations(zg):
+    """src/tests.zig frees its weights (`defer allocator.free`) and allocates same-sized buffers next: a host
+    address that once held a registered weight may come back as an `inputs` slice.  Activations must never be
+    looked up in the registry, and a parameter is only matched with its exact length."""
+    k, n, m = 64, 48, 48  # weight [n, k] and inputs [m, k] have the same byte size
+    w = synth.fill_normal(1, n * k, 0, 0.05).reshape(n, k)
+    buf = np.empty(m * k, np.float32)          # "freed weight" whose address is reused for the inputs
+    buf[:] = synth.fill_normal(2, m * k)
+    _lib.check(zg.zg_register_tensor(buf.ctypes.data, buf.size))
+    buf[:] = synth.fill_normal(3, m * k)       # new contents at the same address: the mirror is now stale
+    x = buf.reshape(m, k)
+    y = z(m, n)
+    ops.Linear(k, n, w, None).forward(x, y)
+    assert_ref_close(oracle.linear_forward(k, n, w, None, x), y, "inputs at a once-registered address", scale_floor=2e-6)
+    # same address as a PARAMETER with a different length: staged, not matched
+    w2 = buf[: (n // 2) * k].reshape(n // 2, k)
+    y2 = z(m, n // 2)
+    xin = synth.fill_normal(4, m * k).reshape(m, k)
+    ops.Linear(k, n // 2, w2, None).forward(xin, y2)
+    assert_ref_close(oracle.linear_forward(k, n // 2, w2, None, xin), y2, "parameter with another length", scale_floor=2e-6)
+    _lib.check(zg.zg_unregister_tensor(buf.ctypes.data))
+    _lib.check(zg.zg_unregister_tensor(buf.ctypes.data))  # idempotent
+
+
 def test_linear_registered_weight_and_device_pointers(zg):
     import torch
 

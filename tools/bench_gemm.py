@@ -18,8 +18,9 @@ def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
     stream = torch.cuda.Stream()
     _lib.check(lib.zg_set_stream(stream.cuda_stream))
     run = lambda: _lib.check(lib.zg_gemm_bf16_nt(a.data_ptr(), b.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, int(gelu), int(out_bf16)))
-    for _ in range(5):
+    for _ in range(400):  # the chip needs tens of milliseconds under load before its clocks settle
         run()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(iters):

@@ -1,19 +1,15 @@
 #!/usr/bin/env python3
-"""Ablation timings of the persistent GEMM (ZGPT2_GEMM_DBG bits: 1 no global stores, 4 no epilogue, 8 no store drain)."""
+"""A/B timings of the persistent GEMM (ZGPT2_GEMM_DBG bits: 1 no global stores, 4 no epilogue, 8 drain the stores,
+16 non-temporal stores)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gemm_check
 from zig_gpt2_amd import _lib
 lib = _lib.load(); _lib.check(lib.zg_init(0))
-for dbg in (0, 8, 1, 9, 4):
+for dbg in [int(a) for a in sys.argv[1:]] or (0, 16, 1, 4):
     os.environ["ZGPT2_GEMM_DBG"] = str(dbg)
     print("dbg", dbg, flush=True)
     gemm_check.time_it(lib, 8192)
     gemm_check.time_it(lib, 8192, gelu=False)
     gemm_check.time_it(lib, 16384)
-os.environ["ZGPT2_GEMM_DBG"] = "0"
-for gw in (4, 8, 16):
-    os.environ["ZGPT2_GW"] = str(gw)
-    print("gw", gw, flush=True)
-    gemm_check.time_it(lib, 8192)

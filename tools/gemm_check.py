@@ -58,8 +58,9 @@ def time_it(lib, m, n=3072, k=768, gelu=True, out_bf16=True, bn=0, iters=50):
     stream = torch.cuda.Stream()
     _lib.check(lib.zg_set_stream(stream.cuda_stream))
     f = lambda: _lib.check(lib.zg_gemm_bf16_nt(a.data_ptr(), b.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, int(gelu), int(out_bf16)))
-    for _ in range(5):
+    for _ in range(400):  # the chip's clocks take tens of milliseconds of load to settle
         f()
+    torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

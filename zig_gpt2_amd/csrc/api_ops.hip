@@ -60,7 +60,13 @@ int Call::alloc(size_t bytes, void** dev) {
     return ZG_OK;
 }
 
-int Call::stage_in(const void* p, size_t bytes, const void** dev) {
+size_t Call::arena_left() const {
+    const Ctx& c = ctx();
+    const size_t off = (c.stage_off + 255) & ~(size_t)255;
+    return off < c.stage_cap ? c.stage_cap - off : 0;
+}
+
+int Call::stage_in(const void* p, size_t bytes, bool is_param, const void** dev) {
     if (bytes == 0 || p == nullptr) {
         *dev = p;
         return ZG_OK;
@@ -69,10 +75,15 @@ int Call::stage_in(const void* p, size_t bytes, const void** dev) {
         *dev = p;
         return ZG_OK;
     }
-    auto it = ctx().registry.find(p);
-    if (it != ctx().registry.end() && it->second.bytes >= bytes) {
-        *dev = it->second.dev;
-        return ZG_OK;
+    // Only parameters may come from the registry, and only on an exact (pointer, size) match: the key is a bare
+    // host address, and host code frees and reuses addresses (the reference's tests allocate same-sized buffers
+    // with page_allocator right after freeing the weights).
+    if (is_param) {
+        auto it = ctx().registry.find(p);
+        if (it != ctx().registry.end() && it->second.bytes == bytes) {
+            *dev = it->second.dev;
+            return ZG_OK;
+        }
     }
     void* d = nullptr;
     ZG_TRY(alloc(bytes, &d));
@@ -121,6 +132,35 @@ struct CallGuard {
         }
     }
 };
+
+// Linear.forward for batch >= 16 on the matrix cores (ops.zig:21-46 with M = inputs.len / in_features, :22).
+// The op tier is fp32 in, fp32 out, arbitrary fp32 weights: both operands are split EXACTLY into three bf16
+// planes (x = hi + mid + lo, 3 x 8 mantissa bits) and the GEMM sums the six plane products whose weight is
+// above 2^-24 of the leading one — every bf16 x bf16 product is exact in fp32 and accumulation is fp32, i.e. the
+// result is fp32-sgemm grade (measured against the oracle at the reference's tolerance in the tests).
+// Order: small products first.
+static bool linear_mfma_ok(size_t in_f, size_t out_f, size_t m, size_t arena_left) {
+    static const bool off = getenv("ZGPT2_NO_LINEAR_MFMA") != nullptr;
+    if (off || m < 16 || in_f < 128 || in_f % 64 != 0 || out_f % 4 != 0) return false;
+    if (m * in_f * 3 >= (1u << 30) || out_f * in_f * 3 >= (1u << 30)) return false;
+    return (m + out_f) * in_f * 3 * sizeof(bf16_t) + 1024 <= arena_left;
+}
+
+static int linear_mfma(Call& call, size_t in_f, size_t out_f, const float* w, const float* bias, const float* x,
+                       size_t m, float* y) {
+    bf16_t *xp, *wp;
+    ZG_TRY(call.scratch(m * in_f * 3, &xp));
+    ZG_TRY(call.scratch(out_f * in_f * 3, &wp));
+    ZG_TRY(launch_split3(x, m, (int)in_f, xp, call.stream()));
+    ZG_TRY(launch_split3(w, out_f, (int)in_f, wp, call.stream()));
+    GemmPlanes pl{};
+    pl.lda = pl.ldb = (int)(3 * in_f);
+    pl.kpp = (int)(in_f / 64);
+    pl.npairs = 6;  // (x plane, w plane): lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi
+    pl.pa_bits = 0x001012u;
+    pl.pb_bits = 0x010210u;
+    return launch_gemm_planes(xp, wp, bias, y, (int)m, (int)out_f, pl, (int)out_f, false, false, call.stream());
+}
 
 static int linear_device(size_t in_f, size_t out_f, const float* w, const float* bias, const float* x,
                          size_t m, float* y, hipStream_t s) {
@@ -266,6 +306,17 @@ int zg_register_tensor(const float* host_ptr, size_t len) {
     return ZG_OK;
 }
 
+int zg_unregister_tensor(const float* host_ptr) {
+    ZG_TRY(require_init());
+    Ctx& c = ctx();
+    auto it = c.registry.find(host_ptr);
+    if (it == c.registry.end()) return ZG_OK;  // never registered (or a device pointer): nothing to drop
+    ZG_HIP(hipStreamSynchronize(c.stream));
+    (void)hipFree(it->second.dev);
+    c.registry.erase(it);
+    return ZG_OK;
+}
+
 int zg_unregister_all(void) {
     ZG_TRY(require_init());
     Ctx& c = ctx();
@@ -290,11 +341,14 @@ int zg_linear_forward(size_t in_features, size_t out_features, const float* weig
     CallGuard guard(call);
     const float *w, *b, *x;
     float* y;
-    ZG_TRY(call.in(weight, in_features * out_features, &w));
-    ZG_TRY(call.in(bias_or_null, out_features, &b));
+    ZG_TRY(call.param(weight, in_features * out_features, &w));
+    ZG_TRY(call.param(bias_or_null, out_features, &b));
     ZG_TRY(call.in(inputs, inputs_len, &x));
     ZG_TRY(call.out(outputs, batch * out_features, &y));
-    ZG_TRY(linear_device(in_features, out_features, w, b, x, batch, y, call.stream()));
+    if (linear_mfma_ok(in_features, out_features, batch, call.arena_left()))
+        ZG_TRY(linear_mfma(call, in_features, out_features, w, b, x, batch, y));
+    else
+        ZG_TRY(linear_device(in_features, out_features, w, b, x, batch, y, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
     return ZG_OK;
@@ -311,6 +365,8 @@ int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_n
     return launch_gemm_bf16_nt(A, B, bias_or_null, C, (int)M, (int)N, (int)K, (int)N, gelu != 0, out_bf16 != 0,
                                ctx().stream);
 }
+
+unsigned long long zg_debug_gemm_launches(void) { return gemm_mfma_launch_count(); }
 
 int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len) {
     ZG_TRY(require_init());
@@ -337,7 +393,7 @@ int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len,
     const float* w;
     const size_t* ix;
     float* out;
-    ZG_TRY(call.in(weight, weight_len, &w));
+    ZG_TRY(call.param(weight, weight_len, &w));
     ZG_TRY(call.in(idxs, idxs_len, &ix));
     ZG_TRY(call.out(embeddings, idxs_len * emb_dim, &out));
     ZG_TRY(launch_embedding(w, emb_dim, ix, idxs_len, weight_len / emb_dim, out, ctx().d_flag, call.stream()));
@@ -358,8 +414,8 @@ int zg_layernorm_forward(size_t n_features, const float* weight, const float* bi
     CallGuard guard(call);
     const float *g, *b;
     float* x;
-    ZG_TRY(call.in(weight, n_features, &g));
-    ZG_TRY(call.in(bias, n_features, &b));
+    ZG_TRY(call.param(weight, n_features, &g));
+    ZG_TRY(call.param(bias, n_features, &b));
     ZG_TRY(call.inout(inputs, inputs_len, &x));
     ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream()));
     ZG_TRY(call.finish());
@@ -489,10 +545,10 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     hipStream_t s = call.stream();
     const float *caw, *cab, *cpw, *cpb, *x;
     float *kc, *vc, *out, *qkv, *q;
-    ZG_TRY(call.in(c_attn_weight, 3 * E * E, &caw));
-    ZG_TRY(call.in(c_attn_bias, 3 * E, &cab));
-    ZG_TRY(call.in(c_proj_weight, E * E, &cpw));
-    ZG_TRY(call.in(c_proj_bias, E, &cpb));
+    ZG_TRY(call.param(c_attn_weight, 3 * E * E, &caw));
+    ZG_TRY(call.param(c_attn_bias, 3 * E, &cab));
+    ZG_TRY(call.param(c_proj_weight, E * E, &cpw));
+    ZG_TRY(call.param(c_proj_bias, E, &cpb));
     ZG_TRY(call.in(inputs, E, &x));
     // Host caches: rows 0..T-2 go up, row T-1 comes back (the caller owns the cache, ops.zig:152,157).
     const bool k_host = !is_device_ptr(k_cache), v_host = !is_device_ptr(v_cache);

@@ -118,6 +118,23 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_
         out[i] = f32_to_bf16_rne(in[i]);
 }
 
+// fp32 [rows][K] -> bf16 planes [rows][3K] = [hi | mid | lo] with hi + mid + lo == x exactly (8 + 8 + 8 mantissa bits):
+// the operand format of launch_gemm_planes.  One thread per 4 consecutive elements (16-B load, three 8-B stores).
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t rows, int K) {
+    const size_t quads = rows * (size_t)(K / 4), stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) {
+        const size_t r = i / (K / 4), k = (i % (K / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + r * K + k);
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3_pk(v.x, v.y, h0, m0, l0);
+        split3_pk(v.z, v.w, h1, m1, l1);
+        bf16_t* o = out + r * (size_t)(3 * K) + k;
+        *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(o + K) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(o + 2 * K) = u32x2{l0, l1};
+    }
+}
+
 __device__ __forceinline__ float load_emb(const void* w, int wt, size_t off) {
     if (wt == WT_BF16) return __uint_as_float((uint32_t)reinterpret_cast<const bf16_t*>(w)[off] << 16);
     return reinterpret_cast<const float*>(w)[off];
@@ -324,6 +341,14 @@ int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s) {
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
     if (n == 0) return ZG_OK;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_split3(const float* in, size_t rows, int K, bf16_t* out, hipStream_t s) {
+    if (rows == 0) return ZG_OK;
+    ZG_REQUIRE(K % 4 == 0, ZG_ERR_UNSUPPORTED, "split3: K=%d must be a multiple of 4", K);
+    hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (size_t)(K / 4))), dim3(256), 0, s, in, out, rows, K);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

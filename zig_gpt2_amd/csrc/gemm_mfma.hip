@@ -133,7 +133,7 @@ __device__ __forceinline__ void tile_of(int idx, int tiles_m, int tiles_n, int g
 template <int BN, bool GELU, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, void* __restrict__ C, int M,
-                                                         int N, int K, int ldc, int tiles_m, int tiles_n, int gw, int dbg) {
+                                                         int N, GemmPlanes pl, int ldc, int tiles_m, int tiles_n, int gw, int dbg) {
     using P = P8<BN>;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -154,16 +154,16 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
 
     // ---- DMA source descriptors and per-lane offsets (constant for the whole kernel, relative to a tile)
     const __amdgpu_buffer_rsrc_t ra =
-        __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * K * 2), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * pl.lda * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb =
-        __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * pl.ldb * 2), 0x00020000);
     // piece = 8 unit rows x 128 B; lane -> unit row r = piece * 8 + lane / 8, LDS position p = lane % 8 holds
     // source chunk p ^ ((r >> 1) & 7)
-    auto rel_off = [&](int piece, int rows_per_wave_half, int tile_dim, int h) -> unsigned {
+    auto rel_off = [&](int piece, int rows_per_wave_half, int tile_dim, int h, int ld) -> unsigned {
         const int r = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int trow = (r / rows_per_wave_half) * tile_dim + h * rows_per_wave_half + r % rows_per_wave_half;
-        return (unsigned)(trow * K + c * 8) * 2u;
+        return (unsigned)(trow * ld + c * 8) * 2u;
     };
     // Per operand ONE per-lane offset (piece `wave` of half 0); the wave's second piece and half 1 are whole rows
     // further (the swizzle term repeats every 16 rows), i.e. wave-uniform byte deltas that go into the scalar
@@ -175,15 +175,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
     auto tile_row = [&](int r, int half_rows, int tile_dim, int h) {  // unit row -> row of the tile
         return (r / half_rows) * tile_dim + h * half_rows + r % half_rows;
     };
-    const unsigned relA = rel_off(wave, P::TM / 2, P::TM, 0), relB = rel_off(wave, P::TN / 2, P::TN, 0);
+    const unsigned relA = rel_off(wave, P::TM / 2, P::TM, 0, pl.lda), relB = rel_off(wave, P::TN / 2, P::TN, 0, pl.ldb);
     unsigned dA[2][2], dB[2][2];  // [half][piece slot] byte deltas (scalars)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int ra0 = tile_row(wave * 8, P::TM / 2, P::TM, 0), rb0 = tile_row(wave * 8, P::TN / 2, P::TN, 0);
-        dA[h][0] = (unsigned)(tile_row(wave * 8, P::TM / 2, P::TM, h) - ra0) * (unsigned)K * 2u;
-        dA[h][1] = (unsigned)(tile_row(pa1 * 8, P::TM / 2, P::TM, h) - ra0) * (unsigned)K * 2u;
-        dB[h][0] = (unsigned)(tile_row(wave * 8, P::TN / 2, P::TN, h) - rb0) * (unsigned)K * 2u;
-        dB[h][1] = (unsigned)(tile_row(pb1[h] * 8, P::TN / 2, P::TN, h) - rb0) * (unsigned)K * 2u;
+        dA[h][0] = (unsigned)(tile_row(wave * 8, P::TM / 2, P::TM, h) - ra0) * (unsigned)pl.lda * 2u;
+        dA[h][1] = (unsigned)(tile_row(pa1 * 8, P::TM / 2, P::TM, h) - ra0) * (unsigned)pl.lda * 2u;
+        dB[h][0] = (unsigned)(tile_row(wave * 8, P::TN / 2, P::TN, h) - rb0) * (unsigned)pl.ldb * 2u;
+        dB[h][1] = (unsigned)(tile_row(pb1[h] * 8, P::TN / 2, P::TN, h) - rb0) * (unsigned)pl.ldb * 2u;
     }
 
     // ---- fragment read addresses: unit row = wr * TM/2 + i * 16 + (lane & 15), 16-B chunk kk * 4 + lane / 16
@@ -192,10 +192,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
     const unsigned a_addr0 = lds_base + (wr * (P::TM / 2) + l15) * 128 + sw0, a_addr1 = a_addr0 ^ 64u;
     const unsigned b_addr0 = lds_base + (wc * (P::TN / 2) + l15) * 128 + sw0, b_addr1 = b_addr0 ^ 64u;
 
-    const int nt = K / 64;
+    // K-steps walk the plane pairs: step kt = pair * kpp + kk multiplies A plane pa[pair] with B plane pb[pair]
+    const int kpp = pl.kpp, nt = pl.kpp * pl.npairs;
+    int pi_cur = 0, kk_cur = 0;  // pair / step inside the pair of the current K-step t
     int tm, tn;
     tile_of(idx, tiles_m, tiles_n, gw, tm, tn);
-    unsigned curA = (unsigned)tm * 256u * (unsigned)K * 2u, curB = (unsigned)tn * BN * (unsigned)K * 2u;
+    const unsigned strideA = 256u * (unsigned)pl.lda * 2u, strideB = (unsigned)BN * (unsigned)pl.ldb * 2u;
+    unsigned curA = (unsigned)tm * strideA, curB = (unsigned)tn * strideB;
     int m0 = tm * 256, n0 = tn * BN;
     constexpr unsigned kOob = 0x80000000u;  // tile base of "no next tile": every lane out of range -> zero fill
     unsigned nxtA = kOob, nxtB = kOob;
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
     int ntm = 0, ntn = 0;
     if (nidx < t_end) {
         tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
-        nxtA = (unsigned)ntm * 256u * (unsigned)K * 2u;
-        nxtB = (unsigned)ntn * BN * (unsigned)K * 2u;
+        nxtA = (unsigned)ntm * strideA;
+        nxtB = (unsigned)ntn * strideB;
     }
 
     // unit of K-step (t + d) of the virtual stream (continues into the next tile) -> buffer X
@@ -213,9 +216,16 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
         constexpr int U = decltype(UT)::value, X = decltype(XT)::value;
         constexpr bool isA = (U == U_A0 || U == U_A1);
         constexpr int h = (U == U_A1 || U == U_B1) ? 1 : 0;
-        const int kt = t + d;
-        const bool in_cur = kt < nt;
-        const unsigned kb = (unsigned)(in_cur ? kt : kt - nt) * 128u;
+        (void)t;
+        int kk = kk_cur + d, pi = pi_cur;  // d <= 2 <= kpp
+        if (kk >= kpp) {
+            kk -= kpp;
+            ++pi;
+        }
+        const bool in_cur = pi < pl.npairs;
+        if (!in_cur) pi = 0;
+        const unsigned plane = ((isA ? pl.pa_bits : pl.pb_bits) >> (4 * pi)) & 15u;
+        const unsigned kb = (plane * (unsigned)kpp + (unsigned)kk) * 128u;
         const unsigned base = isA ? (in_cur ? curA : nxtA) : (in_cur ? curB : nxtB);
         const unsigned dst = lds_base + X * P::BUF + (isA ? P::off_a(h) : P::off_b(h));
         if constexpr (isA) {
@@ -403,7 +413,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
                     const int grow = m0 + wr * P::TM + i * 16 + row;
                     const int gcol = n0 + wc * P::TN + ps * (P::TN / NPASS) + ch * (16 / ESZ);
                     if (grow < M && gcol < N && (!(dbg & 1) || v.x == 0x12345678u))
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(C) + ((size_t)grow * ldc + gcol) * ESZ) = v;
+                    {
+                        u32x4* dstp = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(C) + ((size_t)grow * ldc + gcol) * ESZ);
+                        if (dbg & 16) __builtin_nontemporal_store(v, dstp);  // A/B: measured ~2 us slower at M = 8192
+                        else *dstp = v;
+                    }
                 }
             }
         }
@@ -426,9 +440,18 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
         nxtB = kOob;
         if (nidx < t_end) {
             tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
-            nxtA = (unsigned)ntm * 256u * (unsigned)K * 2u;
-            nxtB = (unsigned)ntn * BN * (unsigned)K * 2u;
+            nxtA = (unsigned)ntm * strideA;
+            nxtB = (unsigned)ntn * strideB;
         }
+    };
+    auto advance = [&]() {  // K-step t -> t + 1; true at the end of the tile
+        if (++kk_cur == kpp) {
+            kk_cur = 0;
+            ++pi_cur;
+        }
+        if (pi_cur < pl.npairs) return false;
+        pi_cur = 0;
+        return true;
     };
 
     // ---- prologue: K-step 0 complete + the first two units of K-step 1, as the steady state expects
@@ -446,14 +469,16 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
     int t = 0;
     for (;;) {
         kstep(I0{}, t);
-        if (++t == nt) {
+        ++t;
+        if (advance()) {
             epilogue();
             if (idx + gx >= t_end) break;
             next_tile();
             t = 0;
         }
         kstep(I1{}, t);
-        if (++t == nt) {
+        ++t;
+        if (advance()) {
             epilogue();
             if (idx + gx >= t_end) break;
             next_tile();
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const bf16_t* __restric
 }
 
 template <int BN, bool GELU, bool OUT_BF16>
-int launch_p8(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, hipStream_t s) {
+int launch_p8(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, hipStream_t s) {
     using P = P8<BN>;
     static bool raised = false;
     if (!raised) {
@@ -479,29 +504,35 @@ int launch_p8(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int 
     const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;  // tests: few workgroups, many tiles each
     const int cus = cus_env > 0 ? cus_env : 256;
     const int grid = n_tiles < cus ? n_tiles : cus;
-    hipLaunchKernelGGL((gemm_p8_kernel<BN, GELU, OUT_BF16>), dim3(grid), dim3(512), P::LDS, s, A, B, bias, C, M, N, K,
+    hipLaunchKernelGGL((gemm_p8_kernel<BN, GELU, OUT_BF16>), dim3(grid), dim3(512), P::LDS, s, A, B, bias, C, M, N, pl,
                        ldc, tiles_m, tiles_n, gw, getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 template <int BN>
-int launch_p8_bn(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, bool gelu,
-                 bool out_bf16, hipStream_t s) {
-    if (gelu) return out_bf16 ? launch_p8<BN, true, true>(A, B, bias, C, M, N, K, ldc, s)
-                              : launch_p8<BN, true, false>(A, B, bias, C, M, N, K, ldc, s);
-    return out_bf16 ? launch_p8<BN, false, true>(A, B, bias, C, M, N, K, ldc, s)
-                    : launch_p8<BN, false, false>(A, B, bias, C, M, N, K, ldc, s);
+int launch_p8_bn(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
+                 bool gelu, bool out_bf16, hipStream_t s) {
+    if (gelu) return out_bf16 ? launch_p8<BN, true, true>(A, B, bias, C, M, N, pl, ldc, s)
+                              : launch_p8<BN, true, false>(A, B, bias, C, M, N, pl, ldc, s);
+    return out_bf16 ? launch_p8<BN, false, true>(A, B, bias, C, M, N, pl, ldc, s)
+                    : launch_p8<BN, false, false>(A, B, bias, C, M, N, pl, ldc, s);
 }
 
 }  // namespace
 
-int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                        bool gelu, bool out_bf16, hipStream_t s) {
-    ZG_REQUIRE(M > 0 && N > 0 && K >= 64 && K % 64 == 0, ZG_ERR_UNSUPPORTED,
-               "gemm_bf16_nt: M=%d N=%d K=%d: K must be a positive multiple of 64", M, N, K);
-    ZG_REQUIRE(N % 8 == 0 && ldc >= N && ldc % 8 == 0, ZG_ERR_UNSUPPORTED, "gemm_bf16_nt: N=%d ldc=%d must be multiples of 8", N, ldc);
-    ZG_REQUIRE((size_t)M * K < (1u << 30) && (size_t)N * K < (1u << 30), ZG_ERR_SHAPE, "gemm_bf16_nt: operand over 2 GiB");
+static unsigned long long g_gemm_launches = 0;
+unsigned long long gemm_mfma_launch_count() { return g_gemm_launches; }
+
+int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl,
+                       int ldc, bool gelu, bool out_bf16, hipStream_t s) {
+    const int K = pl.kpp * 64;
+    ZG_REQUIRE(M > 0 && N > 0 && pl.kpp >= 2 && pl.npairs >= 1 && pl.npairs <= 8, ZG_ERR_UNSUPPORTED,
+               "gemm: M=%d N=%d K=%d pairs=%d: K must be a multiple of 64 and at least 128", M, N, K, pl.npairs);
+    ZG_REQUIRE(pl.lda % 8 == 0 && pl.ldb % 8 == 0 && pl.lda >= K && pl.ldb >= K, ZG_ERR_UNSUPPORTED, "gemm: lda=%d ldb=%d", pl.lda, pl.ldb);
+    const int cq = out_bf16 ? 8 : 4;  // output leaves in 16-byte pieces
+    ZG_REQUIRE(N % cq == 0 && ldc >= N && ldc % cq == 0, ZG_ERR_UNSUPPORTED, "gemm: N=%d ldc=%d must be multiples of %d", N, ldc, cq);
+    ZG_REQUIRE((size_t)M * pl.lda < (1u << 30) && (size_t)N * pl.ldb < (1u << 30), ZG_ERR_SHAPE, "gemm: operand over 2 GiB");
     // tile width: the one that wastes fewer CU-rounds (M = 8192, N = 3072: 512 tiles of 256 x 192 = 2.0 per CU
     // against 384 tiles of 256 x 256 = two rounds with half the chip idle in the second)
     const int bn_env = getenv("ZGPT2_GEMM_BN") ? atoi(getenv("ZGPT2_GEMM_BN")) : 0;
@@ -511,8 +542,20 @@ int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, voi
     };
     int bn = cost(192) < cost(256) ? 192 : 256;
     if (bn_env == 192 || bn_env == 256) bn = bn_env;
-    return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, K, ldc, gelu, out_bf16, s)
-                     : launch_p8_bn<256>(A, B, bias, C, M, N, K, ldc, gelu, out_bf16, s);
+    ++g_gemm_launches;
+    return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
+                     : launch_p8_bn<256>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
+}
+
+int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                        bool gelu, bool out_bf16, hipStream_t s) {
+    ZG_REQUIRE(K >= 128 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "gemm_bf16_nt: K=%d must be a multiple of 64 and at least 128", K);
+    GemmPlanes pl{};
+    pl.lda = K;
+    pl.ldb = K;
+    pl.kpp = K / 64;
+    pl.npairs = 1;
+    return launch_gemm_planes(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
 }
 
 }  // namespace zg

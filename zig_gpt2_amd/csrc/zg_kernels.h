@@ -95,11 +95,27 @@ int launch_split_qkv(const float* in, size_t rows, size_t n_embed, size_t split_
 int launch_transpose(const float* in, size_t batch, size_t t, size_t n, size_t h, float* out, hipStream_t s);
 int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+// fp32 [rows][K] -> bf16 [rows][3K] = [hi | mid | lo], hi + mid + lo == x exactly
+int launch_split3(const float* in, size_t rows, int K, bf16_t* out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ MFMA GEMM
 // C[M,N] = A[M,K] * B[N,K]^T (+ bias) (optional GELU); bf16 operands, fp32 accumulate; C bf16 or fp32.
 int launch_gemm_bf16_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
                         bool gelu, bool out_bf16, hipStream_t s);
+// The same kernel over a list of (A plane, B plane) pairs: A is [M][lda] holding planes of K = 64 kpp columns each
+// (plane p at column p K), B is [N][ldb] likewise; C = sum over pairs of A_plane[pa] * B_plane[pb]^T (+ bias).
+// fp32 operands split exactly into bf16 hi + mid + lo planes make the bf16 matrix cores deliver fp32-grade
+// products (every bf16 x bf16 product is exact in fp32): planes {(2,0),(1,0),(0,0)} for exact-bf16 weights,
+// six pairs for arbitrary fp32 weights.  Pair i's planes sit in bits [4i, 4i + 4) of pa_bits / pb_bits.
+struct GemmPlanes {
+    int lda, ldb;  // row lengths in elements
+    int kpp;       // K-steps (of 64) per plane
+    int npairs;
+    unsigned pa_bits, pb_bits;
+};
+int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl,
+                       int ldc, bool gelu, bool out_bf16, hipStream_t s);
+unsigned long long gemm_mfma_launch_count();  // launches of the MFMA GEMM so far (tests assert the path taken)
 
 // ------------------------------------------------------------------------------------ prefill (prefill.hip)
 // Whole-prompt forward.  Activations feeding a GEMM are fp32 split exactly into kSplit bf16 terms,

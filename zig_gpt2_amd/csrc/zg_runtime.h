@@ -36,10 +36,23 @@ bool is_device_ptr(const void* p);
 class Call {
   public:
     Call();
+    // Activations (inputs, indices, q / k / v): always the caller's bytes of THIS call.
     template <typename T>
     int in(const T* p, size_t n, const T** dev) {
-        return stage_in(p, n * sizeof(T), reinterpret_cast<const void**>(dev));
+        return stage_in(p, n * sizeof(T), false, reinterpret_cast<const void**>(dev));
     }
+    // Borrowed parameters (weights, biases, LayerNorm vectors): a zg_register_tensor mirror of exactly this
+    // pointer AND size is used instead of staging; anything else is staged like an activation.
+    template <typename T>
+    int param(const T* p, size_t n, const T** dev) {
+        return stage_in(p, n * sizeof(T), true, reinterpret_cast<const void**>(dev));
+    }
+    // Device scratch from the same arena (released by finish()).
+    template <typename T>
+    int scratch(size_t n, T** dev) {
+        return alloc(n * sizeof(T), reinterpret_cast<void**>(dev));
+    }
+    size_t arena_left() const;
     template <typename T>
     int out(T* p, size_t n, T** dev) {
         return stage_out(p, n * sizeof(T), false, reinterpret_cast<void**>(dev));
@@ -53,7 +66,7 @@ class Call {
     hipStream_t stream() const { return s_; }
 
   private:
-    int stage_in(const void* p, size_t bytes, const void** dev);
+    int stage_in(const void* p, size_t bytes, bool is_param, const void** dev);
     int stage_out(void* p, size_t bytes, bool copy_in, void** dev);
     int alloc(size_t bytes, void** dev);
     struct Out {

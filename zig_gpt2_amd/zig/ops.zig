@@ -19,6 +19,7 @@ const c = struct {
     extern "c" fn zg_init(device: c_int) c_int;
     extern "c" fn zg_last_error() [*:0]const u8;
     extern "c" fn zg_register_tensor(host_ptr: [*]const f32, len: usize) c_int;
+    extern "c" fn zg_unregister_tensor(host_ptr: [*]const f32) c_int;
     extern "c" fn zg_linear_forward(in_features: usize, out_features: usize, weight: [*]const f32, bias: ?[*]const f32, inputs: [*]const f32, inputs_len: usize, outputs: [*]f32, outputs_len: usize) c_int;
     extern "c" fn zg_embedding_forward(emb_dim: usize, weight: [*]const f32, weight_len: usize, idxs: [*]const usize, idxs_len: usize, embeddings: [*]f32, embeddings_len: usize) c_int;
     extern "c" fn zg_layernorm_forward(n_features: usize, weight: [*]const f32, bias: [*]const f32, eps: f32, inputs: [*]f32, inputs_len: usize) c_int;
@@ -61,6 +62,14 @@ pub const Linear = struct {
         check(c.zg_register_tensor(weight.ptr, weight.len));
         if (bias) |b| check(c.zg_register_tensor(b.ptr, b.len));
         return Self{ .in_features = in_features, .out_features = out_features, .weight = weight, .bias = bias };
+    }
+
+    /// Not in the reference (its structs only borrow): drops the device mirrors before the caller frees the
+    /// weights (`defer allocator.free(...)` in src/tests.zig), so that a reused host address can never meet a
+    /// stale mirror.  Optional: `init` on a new tensor at the same address replaces the mirror anyway.
+    pub fn deinit(self: Self) void {
+        check(c.zg_unregister_tensor(self.weight.ptr));
+        if (self.bias) |b| check(c.zg_unregister_tensor(b.ptr));
     }
 
     pub fn forward(self: Self, inputs: []const f32, outputs: []f32) void {
