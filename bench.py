@@ -39,7 +39,73 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--dry-run", action="store_true",
+                   help="CPU rehearsal of the launch path (gloo, no GPU, no kernels): rendezvous, prompt sharding, "
+                        "weight-arena broadcast, barriers and the max-reduce; prints a line with dry_run=true")
     return p.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a fresh child
+    process BEFORE anything in this process touches the GPU, forward rank 0's JSON line, propagate failure."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    for l in out.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if out.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {a.gpus}-rank launch failed (rc {out.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        sys.exit(out.returncode or 1)
+    d = json.loads(lines[0])
+    if d.get("n_gpus") != a.gpus:
+        print(f"bench.py: asked for {a.gpus} GPUs, the ranks report {d.get('n_gpus')}", file=sys.stderr)
+        sys.exit(1)
+    print(lines[0], flush=True)
+    sys.exit(0)
+
+
+def dry_run(a, rank, world):
+    """The N-rank control flow of main() on CPU: same sharding helpers, same collectives, gloo instead of RCCL."""
+    import torch
+    import torch.distributed as dist
+
+    from zig_gpt2_amd import shard, synth
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = synth.CONFIGS["tiny"]
+    ppg = a.prompts_per_gpu or (1 if world == 1 else 8)
+    n = 1 << 20
+    arena = torch.full((n,), 7, dtype=torch.uint8) if rank == 0 else torch.zeros(n, dtype=torch.uint8)
+    dist.barrier()
+    t0 = time.perf_counter()
+    shard.broadcast_weights(arena, dist, src=0)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    assert int(arena[-1]) == 7
+    mine = shard.shard_prompts(ppg * world, world, rank)
+    assert len(mine) == ppg
+    dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "tokens/sec GPT-2-124M greedy 1024-ctx", "value": 0.0, "unit": "tokens/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dry_run": True, "data": "none (CPU rehearsal of the launch path)",
+                          "config": {"workload": f"dry run, {ppg} prompt(s)/rank x {world} rank(s), model {cfg.n_embed}-wide",
+                                     "prompts_per_gpu": ppg, "global_prompts": ppg * world},
+                          "weight_broadcast_ms": round(bcast_ms, 3), "max_over_ranks_s": float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 class _DevMem:
@@ -106,10 +172,16 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if a.dry_run:
+        return dry_run(a, rank, world)
     import torch
 
     from zig_gpt2_amd import _lib, gpt, shard, synth
@@ -196,29 +268,48 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: ln_f + lm_head GEMV + argmax (31 % of the bytes of a step)
+    # ---- roofline: every kernel class of the decode step timed live (HIP events on the launch stream around a
+    # hipGraph chain of 64 launches of that one kernel, mid-context control block), priced per token by its launch
+    # count; `roofline` describes the class with the LARGEST share of the token time, lm_head and the whole step
+    # are reported beside it.
     wbytes, _ = model.step_bytes(1)
+    wsz = 4 if a.weights_f32 else 2
+    kv_elem = 2 if a.kv_f16 else 4
+    E, L, V = cfg.n_embed, cfg.n_layer, cfg.vocab_size
+    t_mid = max(cfg.context_size // 2, 1)
+    classes = [  # (time_kernel id, name, launches per token, algorithmic bytes per launch)
+        (1, "ln_1 + c_attn + KV append", L, 3 * E * E * wsz),
+        (2, "attention (split-KV decode)", L, 2 * t_mid * E * kv_elem * ppg),
+        (3, "head merge + attn c_proj + residual", L, E * E * wsz),
+        (4, "ln_2 + c_fc + GELU", L, 4 * E * E * wsz),
+        (5, "mlp c_proj + residual", L, 4 * E * E * wsz),
+        (6, "ln_f + lm_head + argmax", 1, V * E * wsz),
+    ]
+    table = []
+    for which, name, n_launch, nbytes in classes:
+        us, _ = model.time_kernel(which, 256)
+        table.append({"class": name, "launches_per_token": n_launch, "avg_launch_us": round(us, 3),
+                      "algorithmic_bytes_per_launch": int(nbytes), "GBps": round(nbytes / us / 1e3, 1),
+                      "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_token": round(us * n_launch, 2)})
+    tot_us = sum(r["us_per_token"] for r in table)
+    for r in table:
+        r["share_of_token_time"] = round(r["us_per_token"] / tot_us, 4)
+    dom = max(table, key=lambda r: r["us_per_token"])
+    lm = table[-1]
     n_prof = min(64, ctx)
     prof_lo = model.profile_step(1, n_prof)
     prof_hi = model.profile_step(ctx - n_prof + 1, n_prof)
-    lm_interval_us = 0.5 * (prof_lo["lnf_lm_head_argmax"] + prof_hi["lnf_lm_head_argmax"])
-    null_us = 0.5 * (prof_lo["null_kernel_interval"] + prof_hi["null_kernel_interval"])
-    # Event pairs around single kernels carry +-3 us of event/boundary overhead at this granularity (the
-    # null-kernel interval is itself ~6 us), so the roofline duration is the per-launch time of 256
-    # back-to-back launches between ONE pair of HIP events (includes the ~1.6 us launch boundary, i.e. it
-    # under-states the rate); the in-situ intervals are reported beside it.
-    lm_bytes = cfg.vocab_size * cfg.n_embed * (4 if a.weights_f32 else 2) * 1.0
-    lm_loop_us, _ = model.time_kernel(_lib.TIME_LM_HEAD, 256)
-    lm_us = lm_loop_us
-    achieved = lm_bytes / (lm_us * 1e-6) / 1e9
-    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): bench.py itself cannot collect counters.
-    traffic, rocprof_us = None, None
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 passes
+    # (profiles/<round>_traffic.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE, per launch, taken at the
+    # same shapes) are quoted with their provenance, null when the file has no entry for this kernel / config.
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "lm_head_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
-        if a.model == "124M" and ppg == 1 and not a.weights_f32:
-            traffic, rocprof_us = tj["traffic_bytes_per_launch"], tj["rocprof_avg_us"]
+        key = f"{a.model}/{ppg}/{'f32' if a.weights_f32 else 'bf16'}"
+        ent = tj.get(key, {}).get(dom["class"])
+        if ent:
+            traffic, traffic_src = ent["bytes_per_launch"], ent["source"]
     except Exception:
         pass
     gemm = None
@@ -250,7 +341,6 @@ def main():
         except Exception as e:
             prefill = {"error": str(e)}
     # whole-step view: algorithmic bytes of all ctx steps / device time
-    kv_elem = 2 if a.kv_f16 else 4
     kv_total = sum(kv_elem * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
     step_bytes_total = wbytes * ctx + kv_total
     out = {
@@ -276,17 +366,17 @@ def main():
             "tokens_counted": "generated tokens (context - prompt) per prompt",
         },
         "roofline": {
-            "kernel": ("gemv_kernel<bf16,M=1,LPR16,CPL6,ARGMAX>" if ppg == 1 else "gemv_mfma_kernel<KS=6,NW=4,ARGMAX>") +
-                      " (ln_f + lm_head + argmax)",
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": int(lm_bytes), "avg_launch_us": round(lm_us, 2),
-            "rocprof_avg_us_committed_profile": rocprof_us,
-            "in_situ_event_interval_us": round(lm_interval_us, 2), "null_kernel_event_interval_us": round(null_us, 2),
-            "how": "256 launches of the kernel replayed back to back from a hipGraph between one pair of HIP events "
-                   "on the launch stream, right after the timed region (launch boundary included); in_situ_* are "
-                   f"event-to-event intervals inside {2 * n_prof} complete decode steps (T=1.. and T={ctx - n_prof + 1}..)",
+            "kernel": dom["class"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac_of_8TBps"], "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
+            "share_of_token_time": dom["share_of_token_time"],
+            "how": "the kernel class with the largest share of the decode-step time; duration = HIP events on the launch "
+                   "stream around a hipGraph chain of that kernel (launch boundary included), measured in this run",
         },
+        "kernel_classes": table,
+        "roofline_lm_head": {"kernel": lm["class"], "achieved": lm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": lm["frac_of_8TBps"], "avg_launch_us": lm["avg_launch_us"],
+                             "algorithmic_bytes_per_launch": lm["algorithmic_bytes_per_launch"]},
         "step_roofline": {
             "bound": "hbm", "algorithmic_bytes_per_generation": int(step_bytes_total),
             "achieved": round(step_bytes_total * a.steps / dev_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
