@@ -42,6 +42,10 @@ struct zg_gpt {
     StepCtrl* ctrl;
     float *x, *q, *h4, *part, *logits, *part_val;
     int *part_idx, *prompt, *prompt_len, *forced, *cur_token, *out_tokens;
+    // split-K combine area of the batched wide Linears (mlp c_proj): [sk_tiles][4][128] floats + one counter per tile
+    float* sk_ws;
+    int* sk_cnt;
+    int sk_tiles;
     // whole-prompt (prefill) scratch, rows = batch * ctx: x fp32 [E], qkv fp32 [3E], split bf16 [kSplit E] and [kSplit 4E]
     float *pf_x, *pf_qkv, *pf_ws;
     size_t pf_ws_floats;
@@ -118,6 +122,9 @@ void carve(zg_gpt* g, char* base) {
     g->forced = (int*)P(B * 4);
     g->cur_token = (int*)P(B * 4);
     g->out_tokens = (int*)P(B * C * 4);
+    g->sk_tiles = (int)((E + 15) / 16);
+    g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
+    g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4);
     if (g->wt == WT_BF16) {
         g->pf_x = (float*)P(B * C * E * 4);
         g->pf_qkv = (float*)P(B * C * 3 * E * 4);
@@ -151,6 +158,9 @@ GemvArgs base_gemv(const zg_gpt* g, const void* W, const float* bias, size_t N, 
     a.max_splits = g->max_splits;
     a.ctx = (int)g->cfg.context_size;
     a.kv_f16 = g->kv_f16;
+    a.sk_ws = g->sk_ws;
+    a.sk_cnt = g->sk_cnt;
+    a.sk_tiles = g->sk_tiles;
     return a;
 }
 
@@ -460,9 +470,17 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         set_error("lm_head grid %d exceeds the argmax partial buffer", g->lm_grid);
         return ZG_ERR_UNSUPPORTED;
     }
-    (void)hipHostMalloc(reinterpret_cast<void**>(&g->h_ctrl), sizeof(StepCtrl), hipHostMallocDefault);
-    (void)hipHostMalloc(reinterpret_cast<void**>(&g->h_ints), (batch * c.context_size + batch) * sizeof(int),
-                        hipHostMallocDefault);
+    g->h_ctrl = nullptr;
+    g->h_ints = nullptr;
+    hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&g->h_ctrl), sizeof(StepCtrl), hipHostMallocDefault);
+    if (he == hipSuccess)
+        he = hipHostMalloc(reinterpret_cast<void**>(&g->h_ints), (batch * c.context_size + batch) * sizeof(int), hipHostMallocDefault);
+    if (he != hipSuccess) {
+        if (g->h_ctrl) (void)hipHostFree(g->h_ctrl);
+        (void)hipFree(g->arena);
+        delete g;
+        return hip_fail(he, "hipHostMalloc(control mirrors)", __FILE__, __LINE__);
+    }
     g->steps_enqueued = 0;
     *out = g;
     return ZG_OK;

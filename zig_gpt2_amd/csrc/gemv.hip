@@ -636,6 +636,105 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     }
 }
 
+// ================================================================================================
+// M == 1, wide un-normalised input (mlp c_proj: K = 4 E): the four waves of a workgroup SPLIT K.
+//
+// In the kernel above a wide input row is as many bytes per wave as the wave's weight rows, so it went through a
+// shared LDS strip behind a barrier — a memory round trip, an LDS round trip and a barrier in front of the first
+// FMA.  Here wave w owns columns [w K/4, (w+1) K/4) of every row of the workgroup: its quarter of the input goes
+// straight from global memory into registers (fetched next to the weights, no LDS, no barrier), every wave streams
+// the same 2 * RPP rows (quarter-row segments of >= 1.5 KB, fully coalesced), and the four partial sums per row
+// meet in LDS after the arithmetic, where one thread per row runs the epilogue.
+template <typename WT, int LPR, int CPL>
+__global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N,
+                                                          int K, int epilogue, const GemvArgs a) {
+    __shared__ float part[4][16];
+    constexpr int RPP = 64 / LPR, ROWS = 2 * RPP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane % LPR, rsub = lane / LPR;
+    const int Kq = K >> 2, nchq = Kq >> 3;
+    const WT* W = reinterpret_cast<const WT*>(Wv) + (size_t)wave * Kq;
+    const int row0 = blockIdx.x * ROWS;
+    const int r0 = row0 + rsub, r1 = row0 + RPP + rsub;
+    // all loads of the kernel up front: two passes of weights, the input quarter, the epilogue operands
+    Raw<WT> wa[CPL], wb[CPL];
+    {
+        const WT* p0 = W + (size_t)min(r0, N - 1) * K;
+        const WT* p1 = W + (size_t)min(r1, N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = min(lr + LPR * i, nchq - 1);
+            wa[i] = load_raw(p0, c);
+            wb[i] = load_raw(p1, c);
+        }
+    }
+    W8 xr[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) xr[i] = load_x8(xin + (size_t)wave * Kq + (size_t)min(lr + LPR * i, nchq - 1) * 8);
+    float bias_n = 0.0f, resid_n = 0.0f;
+    if (tid < ROWS) {
+        const int n = min(row0 + tid, N - 1);
+        bias_n = *(a.bias ? a.bias + n : a.zero);
+        resid_n = *(epilogue == EPI_RESIDUAL ? a.resid + n : a.zero);
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+        if (lr + LPR * i >= nchq) xr[i] = zero_w8();  // clamped surplus chunks multiply zeros
+    auto dot = [&](const Raw<WT>(&w)[CPL]) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const W8 u = unpack(w[i]);
+            p0 = fmaf(u.v[0], xr[i].v[0], p0); p1 = fmaf(u.v[1], xr[i].v[1], p1);
+            p2 = fmaf(u.v[2], xr[i].v[2], p2); p3 = fmaf(u.v[3], xr[i].v[3], p3);
+            p0 = fmaf(u.v[4], xr[i].v[4], p0); p1 = fmaf(u.v[5], xr[i].v[5], p1);
+            p2 = fmaf(u.v[6], xr[i].v[6], p2); p3 = fmaf(u.v[7], xr[i].v[7], p3);
+        }
+        return group_allsum<LPR>((p0 + p1) + (p2 + p3));
+    };
+    const float s0 = dot(wa), s1 = dot(wb);
+    if (lr == 0) {
+        part[wave][rsub] = s0;
+        part[wave][RPP + rsub] = s1;
+    }
+    __syncthreads();
+    if (tid < ROWS && row0 + tid < N) {
+        const int n = row0 + tid;
+        const float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + bias_n;
+        a.y[n] = epilogue == EPI_RESIDUAL ? v + resid_n : (epilogue == EPI_GELU ? gelu_ref(v) : v);
+    }
+}
+
+template <typename WT>
+int launch_ksplit(const GemvArgs& a, hipStream_t s) {
+    const int nchq = a.K / 32;  // 16-B chunks per quarter row
+#define ZG_KS(LPR_, CPL_)                                                                                                \
+    {                                                                                                                    \
+        constexpr int rows = 2 * (64 / LPR_);                                                                            \
+        hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
+                           a.N, a.K, a.epilogue, a);                                                                     \
+        ZG_HIP(hipGetLastError());                                                                                       \
+        return ZG_OK;                                                                                                    \
+    }
+    if (nchq <= 32 * 3) ZG_KS(32, 3)
+    if (nchq <= 32 * 5) ZG_KS(32, 5)
+    if (nchq <= 32 * 7) ZG_KS(32, 7)
+    if (nchq <= 64 * 4) ZG_KS(64, 4)
+#undef ZG_KS
+    zg::set_error("gemv (K split): K=%d too large", a.K);
+    return ZG_ERR_UNSUPPORTED;
+}
+
+// M == 1 plain Linear over a wide input: the K-split kernel (measured against the shared-strip form in situ)
+bool gemv_use_ksplit(const GemvArgs& a) {
+    static const int off = getenv("ZGPT2_NO_KSPLIT") ? atoi(getenv("ZGPT2_NO_KSPLIT")) : 0;
+    static const int min_k = getenv("ZGPT2_KSPLIT_MIN_K") ? atoi(getenv("ZGPT2_KSPLIT_MIN_K")) : 2048;
+    if (off || a.M != 1 || a.prologue != PRO_NONE) return false;
+    if (a.epilogue != EPI_STORE && a.epilogue != EPI_RESIDUAL && a.epilogue != EPI_GELU) return false;
+    return a.K >= min_k && a.K % 32 == 0 && a.K / 32 <= 256;
+}
+
 // Slow generic fallback for K % 8 != 0 (op tier only): one wave per row, scalar loads.
 template <typename WT>
 __global__ __launch_bounds__(256) void gemv_generic_kernel(const GemvArgs a) {
@@ -702,12 +801,22 @@ __device__ __forceinline__ void store_split4(char* planes, int S, int m, int k, 
 // needs two wave reductions per row and one partial-sum exchange through LDS, and the three-plane split
 // is 8..24 elements per lane.  (The first version gave every thread a column slice of ALL rows: 16 wave
 // reductions and 64 elements of split per thread made the prologue 9k of the kernel's 15k cycles.)
-template <int KS, int NW, bool ARGMAX>
+// KSL > 1: the workgroup handles one of KSL equal K slices (blockIdx.y; the K argument is the slice width, the
+// weight row stride is KSL * K) — for wide, thin matrices (mlp c_proj at 8 sequences: 48 tiles of K = 3072, where a
+// single workgroup per tile spent half of its time staging 8 x 3072 activations).  The slices' partial tiles meet in a
+// workspace and are combined in FIXED slice order by the last workgroup of the tile to arrive.  A template parameter,
+// so that the KSL == 1 kernels are untouched (two more leading scalar arguments cost them 6 % in situ).
+template <int KS, int NW, bool ARGMAX, int KSL = 1>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin,
                                                             int N, int K, int M, int tiles_per_wg, int prologue,
                                                             int epilogue, const float* __restrict__ ln_g,
                                                             const float* __restrict__ ln_b, const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_mf[];
+    const int ldw = K * KSL;
+    if constexpr (KSL > 1) {
+        W += (size_t)blockIdx.y * K;
+        xin += (size_t)blockIdx.y * K;
+    }
     ZG_STAMP_DECL();
     ZG_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -724,7 +833,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     // ---- 0. first tile's weight fragments: independent of everything else
     u32x4 wq[KS];
     auto load_tile = [&](int tile) {
-        const bf16_t* wp = W + (size_t)min(min(tile, ntiles - 1) * 16 + brow, N - 1) * K + bq * 8;
+        const bf16_t* wp = W + (size_t)min(min(tile, ntiles - 1) * 16 + brow, N - 1) * ldw + bq * 8;
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
             const int st = min(wave + NW * i, nsteps - 1);  // surplus steps re-read the last one (weight 0 below)
@@ -894,8 +1003,41 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
                 for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], 32, 64);
             }
             const int n = tile * 16 + brow;
-            if (lane < 32 && n < N) {  // lanes 0..31 hold batch rows 0..7
-                const bool first = tile == tile_begin;
+            bool run_epilogue = true;
+            if constexpr (KSL > 1) {
+                // Publish this slice's tile with write-through (agent-scope relaxed atomic = sc1) stores, drain them, take
+                // a ticket; the last arriver reads all slices back with agent-scope loads and adds them in slice order.
+                // No release / acquire fences: a fence pair (buffer_wbl2 + buffer_inv) cost 1.8 us of a 5 us kernel.
+                typedef __attribute__((address_space(1))) unsigned gu32;
+                gu32* slot = (gu32*)(a.sk_ws + ((size_t)tile * KSL + blockIdx.y) * 128);
+                if (lane < 32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(slot + lane * 4 + r, __float_as_uint(sum[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int ticket = 0;
+                if (lane == 0) ticket = __hip_atomic_fetch_add(a.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = __builtin_amdgcn_readfirstlane(ticket);
+                run_epilogue = ticket == KSL - 1;
+                if (run_epilogue) {
+                    const gu32* base = (const gu32*)(a.sk_ws + (size_t)tile * KSL * 128) + (lane & 31) * 4;
+                    unsigned bits[KSL][4];
+#pragma unroll
+                    for (int ks = 0; ks < KSL; ++ks)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            bits[ks][r] = __hip_atomic_load(base + ks * 128 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sum = mf_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int ks = 0; ks < KSL; ++ks)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[r] += __uint_as_float(bits[ks][r]);
+                    if (lane == 0) __hip_atomic_store(a.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+                }
+            }
+            if (run_epilogue && lane < 32 && n < N) {  // lanes 0..31 hold batch rows 0..7
+                const bool first = KSL == 1 && tile == tile_begin;
                 const float bias_n = first ? pre_bias : (a.bias ? a.bias[n] : 0.0f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -944,29 +1086,35 @@ inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false) {
 
 // single-tile workgroups may let the partial tiles alias the planes (see the kernel)
 inline bool gemv_mfma_alias(const GemvArgs& a) {
-    return a.epilogue != EPI_ARGMAX && a.rows_per_wave == 1 && gemv_mfma_lds(a.K, 16) > 160 * 1024;
+    return a.kslices <= 1 && a.epilogue != EPI_ARGMAX && a.rows_per_wave == 1 && gemv_mfma_lds(a.K, 16) > 160 * 1024;
 }
 
-template <int KS, int NW, bool ARGMAX>
+template <int KS, int NW, bool ARGMAX, int KSL = 1>
 int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
-    const bool alias = gemv_mfma_alias(a);
-    const size_t lds = gemv_mfma_lds(a.K, NW, alias);
+    const bool alias = KSL == 1 && gemv_mfma_alias(a);
+    const size_t lds = gemv_mfma_lds(a.K / KSL, NW, alias);
     GemvArgs b = a;
     b.waves_per_wg = alias ? -1 : NW;  // < 0: partial tiles alias the planes
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX, KSL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX>), dim3(grid), dim3(NW * 64), lds, s,
-                       reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K, a.M, a.rows_per_wave, a.prologue,
+    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX, KSL>), dim3(grid, KSL), dim3(NW * 64), lds, s,
+                       reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K / KSL, a.M, a.rows_per_wave, a.prologue,
                        a.epilogue, a.ln_g, a.ln_b, b);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
+    if (a.kslices == 4) {  // four K slices over four workgroups per tile (gemv_kslices)
+        const int ks = (a.K / 4 / 32 + 15) / 16;
+        if (ks <= 2) return launch_mfma_inst<2, 16, false, 4>(a, grid, s);
+        if (ks <= 4) return launch_mfma_inst<4, 16, false, 4>(a, grid, s);
+        return launch_mfma_inst<6, 16, false, 4>(a, grid, s);
+    }
     const int steps = a.K / 32;
     if (a.epilogue == EPI_ARGMAX) {  // lm_head: 4 waves
         const int ks = (steps + 3) / 4;
@@ -1050,6 +1198,16 @@ int gemv_lanes_per_row(int K) {
     return 64;
 }
 
+// Wide, thin, un-normalised Linears of the lock-step batch (mlp c_proj) are cut into four K slices over as many
+// workgroups when the caller provided the combine workspace.
+int gemv_kslices(const GemvArgs& a) {
+    static const int off = getenv("ZGPT2_NO_SPLITK") ? atoi(getenv("ZGPT2_NO_SPLITK")) : 0;
+    if (off || a.sk_ws == nullptr || a.sk_cnt == nullptr || a.M < 2 || a.M > kMfmaRows) return 1;
+    if (a.prologue != PRO_NONE || a.epilogue == EPI_ARGMAX || a.epilogue == EPI_QKV) return 1;
+    if (a.K < 2048 || a.K % 128 != 0 || a.K / 4 > 3072 || (a.N + 15) / 16 > a.sk_tiles) return 1;
+    return 4;
+}
+
 // Rows per wave: enough waves to cover the chip (256 CUs x 4 SIMDs x 2) without dropping below
 // one double pass (2 * 64/LPR rows) per wave.
 // The matrix-core path serves the model tier's lock-step batch: bf16 weights, 2..8 rows, K a
@@ -1057,6 +1215,7 @@ int gemv_lanes_per_row(int K) {
 bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
     static const int off = getenv("ZGPT2_NO_GEMV_MFMA") ? atoi(getenv("ZGPT2_NO_GEMV_MFMA")) : 0;
     if (off || weight_type != WT_BF16 || a.M < 2 || a.M > kMfmaRows) return false;
+    if (gemv_kslices(a) > 1) return true;
     if (a.K % 32 != 0 || a.K / 32 < 4 || a.K / 32 > 96) return false;
     if (a.prologue == PRO_LAYERNORM && a.K > 2048) return false;
     if (gemv_mfma_lds(a.K, gemv_mfma_waves(a)) <= 160 * 1024) return true;
@@ -1090,6 +1249,11 @@ bool gemv_supported(const GemvArgs& a, int weight_type) {
 int gemv_plan(GemvArgs& a, int weight_type) {
     if (gemv_use_mfma(a, weight_type)) {
         const int ntiles = (a.N + 15) / 16;
+        a.kslices = gemv_kslices(a);
+        if (a.kslices > 1) {  // one tile per workgroup and slice
+            a.rows_per_wave = 1;
+            return ntiles;
+        }
         static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
         int tpw = (ntiles + wgs - 1) / wgs;  // at most ~4 workgroups per CU for the widest matrices
         if (tpw < 1) tpw = 1;
@@ -1123,6 +1287,7 @@ int gemv_plan(GemvArgs& a, int weight_type) {
 
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
     if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);
+    if (gemv_use_ksplit(a)) return weight_type == WT_BF16 ? launch_ksplit<bf16_t>(a, s) : launch_ksplit<float>(a, s);
     if (a.M > 1 && valu_lds(valu_mt(a.M), a.K) > 160 * 1024 && splittable(a)) {
         const int g = row_group(a);
         for (int m0 = 0; m0 < a.M; m0 += g) {

@@ -56,6 +56,12 @@ struct GemvArgs {
     int logits_stride;
     float* part_val;
     int* part_idx;
+    // split-K over workgroups (batched wide Linears): combine workspace [sk_tiles][4][128] floats and one counter per
+    // tile (zero between launches: the last arriver resets its tile's counter); kslices is filled by gemv_plan
+    float* sk_ws;
+    int* sk_cnt;
+    int sk_tiles;
+    int kslices;
     const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
 };
@@ -64,6 +70,7 @@ struct GemvArgs {
 bool gemv_supported(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
+int gemv_kslices(const GemvArgs& a);
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ attention
