@@ -155,7 +155,54 @@ def test_prefill_errors(zg):
     with pytest.raises(_lib.ZgError):
         m.prefill([[cfg.vocab_size]])
     m.close()
-    f = zgpt.GPT(cfg, weights_f32=True)
+    f = zgpt.GPT(cfg, prefill=False)  # ZG_GPT_NO_PREFILL: no whole-prompt buffers in the arena
     with pytest.raises(_lib.ZgError):
         f.prefill([[1, 2, 3]])
     f.close()
+
+
+@pytest.mark.parametrize("name,lengths", [("tiny", [1, 5, 33, 64]), ("tiny3", [7, 48]), ("xl-slice", [40])])
+def test_prefill_with_fp32_weights(zg, name, lengths):
+    """ZG_GPT_WEIGHTS_F32 handles (checkpoints that are not bf16-representable): the whole-prompt pass multiplies exact
+    bf16 plane triples of BOTH operands (six plane products) and must meet the same tolerance against the fp32 oracle
+    as the decode path; the decode step on top pins the cache contents."""
+    cfg = synth.CONFIGS[name]
+    w = synth.make_weights(cfg, seed=73, bf16=False)
+    m = zgpt.GPT(cfg, weights_f32=True)
+    m.load_weights(w)
+    for n in lengths:
+        toks = synth.rand_tokens(730 + n, min(n + 1, cfg.context_size), cfg.vocab_size)
+        lg_ref = oracle.GPT(cfg, w).forced_logits(toks, n - 1)
+        lg = m.prefill([toks[:n]])
+        assert_model_close(lg_ref[0], lg[0], f"{name} fp32-weight prefill n={n}")
+        if n < cfg.context_size:
+            assert_model_close(lg_ref[1], m.forward(n + 1, [toks[n]])[0], f"{name} decode after fp32-weight prefill n={n}")
+    # generate() uses the pass for the prompt and must reproduce the oracle's greedy tokens
+    prompt = synth.rand_tokens(739, 9, cfg.vocab_size)
+    n_steps = min(40, cfg.context_size)
+    ids = m.generate([prompt], n_steps)[0]
+    ids_ref, lgs = oracle.GPT(cfg, w).generate_greedy(prompt, n_steps, want_logits=True)
+    top = np.sort(lgs, axis=1)
+    assert_greedy_ids_match(ids_ref[9:], ids[9:], top[:, -1], top[:, -2], f"{name} fp32 weights generate")
+    m.close()
+
+
+def test_prefill_two_plane_mode_is_inside_the_parity_bound(zg):
+    """ZG_GPT_PREFILL_2PLANE: hi + mid planes of the activations only.  north_star's bound is 1e-3 relative; the
+    two-plane error is ~2e-5 of the logit scale, so it is stated against the logit scale (not against the
+    near-zero floor of assert_model_close, which the exact three-plane default meets)."""
+    cfg = synth.CONFIGS["124M"]
+    w = synth.make_weights(cfg, seed=74, bf16=True)
+    toks = synth.rand_tokens(741, 96, cfg.vocab_size)
+    m3 = zgpt.GPT(cfg)
+    m3.load_weights(w)
+    lg3 = m3.prefill([toks])[0]
+    m3.close()
+    m2 = zgpt.GPT(cfg, prefill_planes=2)
+    m2.load_weights(w)
+    lg2 = m2.prefill([toks])[0]
+    m2.close()
+    scale = float(np.abs(lg3).max())
+    err = float(np.abs(lg2 - lg3).max()) / scale
+    assert 0 < err < 1e-3, err
+    assert int(np.argmax(lg2)) == int(np.argmax(lg3))

@@ -78,7 +78,7 @@ SIGNATURES = {
 }
 
 # flags / slots of include/zgpt2.h
-GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL = 0, 1, 2, 4, 8
+GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL, GPT_PREFILL_2PLANE = 0, 1, 2, 4, 8, 16
 BLOCK_SLOTS = ["ln_1_g", "ln_1_b", "c_attn_w", "c_attn_b", "c_proj_w", "c_proj_b",
                "ln_2_g", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b"]
 TOP_SLOTS = ["wte", "wpe", "ln_f_g", "ln_f_b"]

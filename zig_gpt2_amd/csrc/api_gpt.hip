@@ -22,6 +22,9 @@ using namespace zg;
 
 struct zg_layer {
     void *c_attn_w, *c_proj_w, *c_fc_w, *mlp_proj_w;
+    // ZG_GPT_WEIGHTS_F32 handles only: the same matrices split exactly into bf16 planes [out][3 in] = [hi | mid | lo]
+    // (filled when the tensor is loaded) — the B operand of the whole-prompt GEMMs
+    bf16_t *c_attn_p, *c_proj_p, *c_fc_p, *mlp_proj_p;
     float *ln_1_g, *ln_1_b, *c_attn_b, *c_proj_b, *ln_2_g, *ln_2_b, *c_fc_b, *mlp_proj_b;
     void *k_cache, *v_cache;
 };
@@ -103,6 +106,13 @@ void carve(zg_gpt* g, char* base) {
         y.ln_2_b = (float*)P(E * 4);
         y.c_fc_b = (float*)P(4 * E * 4);
         y.mlp_proj_b = (float*)P(E * 4);
+        y.c_attn_p = y.c_proj_p = y.c_fc_p = y.mlp_proj_p = nullptr;
+        if (g->wt == WT_F32 && !(g->flags & ZG_GPT_NO_PREFILL)) {  // inside the weight region: broadcast with the weights
+            y.c_attn_p = (bf16_t*)P(3 * E * E * kSplit * 2);
+            y.c_proj_p = (bf16_t*)P(E * E * kSplit * 2);
+            y.c_fc_p = (bf16_t*)P(4 * E * E * kSplit * 2);
+            y.mlp_proj_p = (bf16_t*)P(4 * E * E * kSplit * 2);
+        }
     }
     g->weight_region_bytes = (cv.off + 255) & ~(size_t)255;
     for (size_t l = 0; l < L; ++l) {
@@ -125,12 +135,16 @@ void carve(zg_gpt* g, char* base) {
     g->sk_tiles = (int)((E + 15) / 16);
     g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
     g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4);
-    if (g->wt == WT_BF16) {
+    g->pf_x = g->pf_qkv = g->pf_ws = nullptr;
+    g->pf_a = g->pf_h = nullptr;
+    g->pf_ws_floats = 0;
+    if (!(g->flags & ZG_GPT_NO_PREFILL)) {
         g->pf_x = (float*)P(B * C * E * 4);
         g->pf_qkv = (float*)P(B * C * 3 * E * 4);
         g->pf_a = (bf16_t*)P(B * C * kSplit * E * 2);
         g->pf_h = (bf16_t*)P(B * C * kSplit * 4 * E * 2);
-        g->pf_ws_floats = 16u << 20;  // 64 MiB of split-K partial sums
+        // bf16 weights: 64 MiB of split-K partial sums; fp32 weights: a full fp32 [rows][4 E] GEMM output
+        g->pf_ws_floats = g->wt == WT_BF16 ? (size_t)(16u << 20) : B * C * 4 * E;
         g->pf_ws = (float*)P(g->pf_ws_floats * 4);
     }
     g->arena_bytes = (cv.off + 255) & ~(size_t)255;
@@ -323,7 +337,47 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
 // exactly as P calls of GPT.forward would (main.zig:331-334) and leaves the residual stream of all rows in
 // pf_x.  With `last_block_full` false the last Block stops after its cache append: nothing downstream of
 // it is needed when generation re-feeds the last prompt token (main.zig:337).
+// fp32 weights (ZG_GPT_WEIGHTS_F32): the same pass with both GEMM operands as exact bf16 plane triples — the six
+// plane products above 2^-24 of the leading one on the persistent MFMA GEMM (launch_gemm_planes), i.e. fp32-sgemm
+// grade Linears for checkpoints that are not bf16-representable; epilogues run as separate small kernels.
+int enqueue_prefill_f32(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
+    const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
+    const int B = (int)g->batch, M = (int)(g->batch * P), iE = (int)E;
+    auto planes = [&](int K) {
+        GemmPlanes pl{};
+        pl.lda = pl.ldb = kSplit * K;
+        pl.kpp = K / 64;
+        pl.npairs = 6;  // (x, w): lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi — smallest products first
+        pl.pa_bits = 0x001012u;
+        pl.pb_bits = 0x010210u;
+        return pl;
+    };
+    ZG_REQUIRE(E % 64 == 0 && E >= 128, ZG_ERR_UNSUPPORTED, "prefill with fp32 weights needs n_embed a multiple of 64 (>= 128)");
+    ZG_TRY(launch_embed_prefill(g->prompt, (int)C, B, (int)P, g->wte, g->wpe, g->wt, iE, g->pf_x, s));
+    ZG_TRY(launch_ln_split(g->pf_x, M, iE, g->layers[0].ln_1_g, g->layers[0].ln_1_b, 1e-5f, g->pf_a, s));
+    for (size_t l = 0; l < L; ++l) {
+        const zg_layer& y = g->layers[l];
+        const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_f16, y.k_cache, y.v_cache};
+        ZG_TRY(launch_gemm_planes(g->pf_a, y.c_attn_p, y.c_attn_b, g->pf_qkv, M, 3 * iE, planes(iE), 3 * iE, false, false, s));
+        ZG_TRY(launch_qkv_scatter(g->pf_qkv, M, qa, s));  // cache append of ops.zig:152-157
+        if (l + 1 == L && !last_block_full) break;
+        ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
+        const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
+        ZG_TRY(launch_gemm_planes(g->pf_a, y.c_proj_p, y.c_proj_b, g->pf_ws, M, iE, planes(iE), iE, false, false, s));
+        ZG_TRY(launch_resid_ln(g->pf_ws, g->pf_x, M, iE, &ln2, s));
+        ZG_TRY(launch_gemm_planes(g->pf_a, y.c_fc_p, y.c_fc_b, g->pf_ws, M, 4 * iE, planes(iE), 4 * iE, true, false, s));
+        ZG_TRY(launch_split3(g->pf_ws, (size_t)M, 4 * iE, g->pf_h, s));
+        const bool more = l + 1 < L;
+        const PrefillLn ln1{more ? g->layers[l + 1].ln_1_g : nullptr, more ? g->layers[l + 1].ln_1_b : nullptr, 1e-5f, g->pf_a};
+        ZG_TRY(launch_gemm_planes(g->pf_h, y.mlp_proj_p, y.mlp_proj_b, g->pf_ws, M, iE, planes(4 * iE), iE, false, false, s));
+        ZG_TRY(launch_resid_ln(g->pf_ws, g->pf_x, M, iE, more ? &ln1 : nullptr, s));
+    }
+    return ZG_OK;
+}
+
 int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
+    if (g->wt == WT_F32) return enqueue_prefill_f32(g, P, last_block_full, s);
+    const int np = (g->flags & ZG_GPT_PREFILL_2PLANE) ? 2 : kSplit;
     const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
     const int B = (int)g->batch, M = (int)(g->batch * P), iE = (int)E;
     ZG_TRY(launch_embed_prefill(g->prompt, (int)C, B, (int)P, g->wte, g->wpe, g->wt, iE, g->pf_x, s));
@@ -334,18 +388,18 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         // c_attn with the cache append of ops.zig:152-157 in its epilogue
         const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_f16, y.k_cache, y.v_cache};
         ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
-                                   g->pf_ws, g->pf_ws_floats, nullptr, s, &qa));
+                                   g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
         ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
         const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
         ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
-                                   g->pf_ws_floats, &ln2, s));
+                                   g->pf_ws_floats, &ln2, s, nullptr, np));
         ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, g->pf_ws,
-                                   g->pf_ws_floats, nullptr, s));
+                                   g->pf_ws_floats, nullptr, s, nullptr, np));
         const bool more = l + 1 < L;
         const PrefillLn ln1{more ? g->layers[l + 1].ln_1_g : nullptr, more ? g->layers[l + 1].ln_1_b : nullptr, 1e-5f, g->pf_a};
         ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws,
-                                   g->pf_ws_floats, more ? &ln1 : nullptr, s));
+                                   g->pf_ws_floats, more ? &ln1 : nullptr, s, nullptr, np));
     }
     return ZG_OK;
 }
@@ -365,28 +419,47 @@ void drop_graphs(zg_gpt* g) {
 
 // Run one decode step at sequence length seq_len: replay the graph of its bucket (capturing it on
 // first use), or launch eagerly when graphs are disabled / the stream cannot be captured.
-int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
-    const int t_hi = bucket_t_hi(g, seq_len);
-    if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_step(g, with_logits, t_hi, s);
+int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
+    const size_t seq_len = (idx / 2 + 1) * 64;  // any length of the bucket: only its upper bound is baked in
+    const bool with_logits = idx & 1;
+    if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
+    if (g->graphs[idx]) return ZG_OK;
+    hipGraph_t graph = nullptr;
+    ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int st = enqueue_step(g, with_logits, bucket_t_hi(g, seq_len), s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (st != ZG_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return st;
+    }
+    ZG_HIP(e);
+    ZG_HIP(hipGraphInstantiate(&g->graphs[idx], graph, nullptr, nullptr, 0));
+    ZG_HIP(hipGraphDestroy(graph));
+    return ZG_OK;
+}
+
+// All decode graphs of a handle (two per 64-position bucket: with / without lm_head) for stream s.  Called from
+// zg_gpt_create — the State.init moment (main.zig:46-64) — so that no forward allocates; a later zg_set_stream
+// re-captures them on the first call that sees the new stream.
+int capture_all(zg_gpt* g, hipStream_t s) {
+    if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return ZG_OK;
     if (g->graph_stream != s) {
         drop_graphs(g);
         g->graph_stream = s;
     }
+    const size_t n = ((g->cfg.context_size + 63) / 64) * 2;
+    for (size_t idx = 0; idx < n; ++idx) ZG_TRY(capture_bucket(g, idx, s));
+    return ZG_OK;
+}
+
+// Run one decode step at sequence length seq_len: replay the graph of its bucket, or launch eagerly when graphs
+// are disabled / the stream cannot be captured.
+int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
+    const int t_hi = bucket_t_hi(g, seq_len);
+    if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_step(g, with_logits, t_hi, s);
+    if (g->graph_stream != s) ZG_TRY(capture_all(g, s));  // the caller switched streams after zg_gpt_create
     const size_t idx = ((seq_len + 63) / 64 - 1) * 2 + (with_logits ? 1 : 0);
-    if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
-    if (!g->graphs[idx]) {
-        hipGraph_t graph = nullptr;
-        ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int st = enqueue_step(g, with_logits, t_hi, s);
-        hipError_t e = hipStreamEndCapture(s, &graph);
-        if (st != ZG_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return st;
-        }
-        ZG_HIP(e);
-        ZG_HIP(hipGraphInstantiate(&g->graphs[idx], graph, nullptr, nullptr, 0));
-        ZG_HIP(hipGraphDestroy(graph));
-    }
+    ZG_TRY(capture_bucket(g, idx, s));  // no-op: captured at create
     ZG_HIP(hipGraphLaunch(g->graphs[idx], s));
     return ZG_OK;
 }
@@ -482,6 +555,17 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         return hip_fail(he, "hipHostMalloc(control mirrors)", __FILE__, __LINE__);
     }
     g->steps_enqueued = 0;
+    {   // every decode graph is captured and instantiated here, not on the first forward that needs it
+        const int st = capture_all(g, ctx().stream);
+        if (st != ZG_OK) {
+            drop_graphs(g);
+            (void)hipHostFree(g->h_ctrl);
+            (void)hipHostFree(g->h_ints);
+            (void)hipFree(g->arena);
+            delete g;
+            return st;
+        }
+    }
     *out = g;
     return ZG_OK;
 }
@@ -521,7 +605,14 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
         default: ZG_REQUIRE(false, ZG_ERR_ARG, "unknown block slot %d", slot);
     }
     ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "block slot %d expects %zu elements, got %zu", slot, n, len);
-    return upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream);
+    ZG_TRY(upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream));
+    if (mat && g->wt == WT_F32 && y.c_attn_p) {  // exact bf16 planes of the fp32 matrix for the whole-prompt GEMMs
+        bf16_t* pl = slot == ZG_C_ATTN_W ? y.c_attn_p : slot == ZG_C_PROJ_W ? y.c_proj_p : slot == ZG_C_FC_W ? y.c_fc_p : y.mlp_proj_p;
+        const int K = (slot == ZG_MLP_PROJ_W) ? (int)(4 * E) : (int)E;
+        ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), n / (size_t)K, K, pl, ctx().stream));
+        ZG_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    return ZG_OK;
 }
 
 int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len) {
@@ -593,7 +684,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
                    float* logits_out, size_t logits_len) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && tokens, ZG_ERR_ARG, "gpt_prefill: null argument");
-    ZG_REQUIRE(g->wt == WT_BF16, ZG_ERR_UNSUPPORTED, "gpt_prefill needs bf16 weights (handle created with ZG_GPT_WEIGHTS_F32)");
+    ZG_REQUIRE(g->pf_x != nullptr, ZG_ERR_UNSUPPORTED, "gpt_prefill: the handle was created with ZG_GPT_NO_PREFILL");
     const size_t C = g->cfg.context_size, V = g->cfg.vocab_size, B = g->batch, E = g->cfg.n_embed;
     ZG_REQUIRE(n_tokens >= 1 && n_tokens <= C && n_tokens <= token_stride, ZG_ERR_SHAPE,
                "gpt_prefill: n_tokens %zu outside 1..%zu (stride %zu)", n_tokens, C, token_stride);
@@ -704,7 +795,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     // The positions every sequence has a prompt token for go through the Blocks together (prefill); the
     // rest of the loop is main.zig:330-338 one position at a time.
     size_t first = 0;
-    if (g->wt == WT_BF16 && !(g->flags & ZG_GPT_NO_PREFILL) && min_prompt >= prefill_min())
+    if (g->pf_x != nullptr && min_prompt >= prefill_min())
         first = min_prompt < n_steps ? min_prompt : n_steps;
     g->h_ctrl->step = (int)first;
     g->h_ctrl->seq_len = (int)first;

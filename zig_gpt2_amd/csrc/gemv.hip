@@ -130,6 +130,8 @@ __device__ __forceinline__ Best wave_best(Best b) {
 
 template <typename KV>
 __device__ __forceinline__ void kv_store(void* cache, size_t off, float v) {
+    // fp16 cache: saturate instead of overflowing to inf (a masked position holding inf would turn p = 0 into NaN)
+    if (sizeof(KV) == 2) v = fminf(fmaxf(v, -65504.0f), 65504.0f);
     reinterpret_cast<KV*>(cache)[off] = (KV)v;
 }
 
