@@ -25,6 +25,8 @@ struct zg_layer {
     // ZG_GPT_WEIGHTS_F32 handles only: the same matrices split exactly into bf16 planes [out][3 in] = [hi | mid | lo]
     // (filled when the tensor is loaded) — the B operand of the whole-prompt GEMMs
     bf16_t *c_attn_p, *c_proj_p, *c_fc_p, *mlp_proj_p;
+    // LayerNorm folded out of the two LayerNorm-fed Linears (gemv.hip, gemv_lnk_kernel): c2 = W g, c3 = W b + bias
+    float *c_attn_c2, *c_attn_c3, *c_fc_c2, *c_fc_c3;
     float *ln_1_g, *ln_1_b, *c_attn_b, *c_proj_b, *ln_2_g, *ln_2_b, *c_fc_b, *mlp_proj_b;
     void *k_cache, *v_cache;
 };
@@ -63,6 +65,7 @@ struct zg_gpt {
     std::vector<hipGraphExec_t> graphs;
     hipStream_t graph_stream;
     size_t steps_enqueued;
+    bool ln_folded;  // c2 / c3 of every layer match the weights currently in the arena
 };
 
 namespace {
@@ -106,6 +109,10 @@ void carve(zg_gpt* g, char* base) {
         y.ln_2_b = (float*)P(E * 4);
         y.c_fc_b = (float*)P(4 * E * 4);
         y.mlp_proj_b = (float*)P(E * 4);
+        y.c_attn_c2 = (float*)P(3 * E * 4);
+        y.c_attn_c3 = (float*)P(3 * E * 4);
+        y.c_fc_c2 = (float*)P(4 * E * 4);
+        y.c_fc_c3 = (float*)P(4 * E * 4);
         y.c_attn_p = y.c_proj_p = y.c_fc_p = y.mlp_proj_p = nullptr;
         if (g->wt == WT_F32 && !(g->flags & ZG_GPT_NO_PREFILL)) {  // inside the weight region: broadcast with the weights
             y.c_attn_p = (bf16_t*)P(3 * E * E * kSplit * 2);
@@ -241,6 +248,19 @@ inline int prof_mark(StepProf* p, int cls, hipStream_t s) {
     return ZG_OK;
 }
 
+// (Re)derive the folded-LayerNorm vectors from the weights in the arena: after loading, or on ranks that received
+// the weight region by broadcast.  A handful of small launches outside any graph.
+int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
+    if (g->ln_folded) return ZG_OK;
+    const int E = (int)g->cfg.n_embed;
+    for (const zg_layer& y : g->layers) {
+        ZG_TRY(launch_ln_fold(y.c_attn_w, g->wt, y.ln_1_g, y.ln_1_b, y.c_attn_b, 3 * E, E, y.c_attn_c2, y.c_attn_c3, s));
+        ZG_TRY(launch_ln_fold(y.c_fc_w, g->wt, y.ln_2_g, y.ln_2_b, y.c_fc_b, 4 * E, E, y.c_fc_c2, y.c_fc_c3, s));
+    }
+    g->ln_folded = true;
+    return ZG_OK;
+}
+
 // One decode step = GPT.forward (main.zig:178-195) for all sequences.
 // `only` >= 0 (measurement): launch just that kernel class of layer 0.
 int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1) {
@@ -257,6 +277,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.x_stride = (int)E;
             a.ln_g = y.ln_1_g;
             a.ln_b = y.ln_1_b;
+            a.ln_c2 = y.c_attn_c2;
+            a.ln_c3 = y.c_attn_c3;
             a.epilogue = EPI_QKV;
             a.q = g->q;
             a.k_cache = y.k_cache;
@@ -304,6 +326,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.x_stride = (int)E;
             a.ln_g = y.ln_2_g;
             a.ln_b = y.ln_2_b;
+            a.ln_c2 = y.c_fc_c2;
+            a.ln_c3 = y.c_fc_c3;
             a.epilogue = EPI_GELU;
             a.y = g->h4;
             a.y_stride = (int)(4 * E);
@@ -455,6 +479,7 @@ int capture_all(zg_gpt* g, hipStream_t s) {
 // Run one decode step at sequence length seq_len: replay the graph of its bucket, or launch eagerly when graphs
 // are disabled / the stream cannot be captured.
 int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
+    ZG_TRY(ensure_ln_folded(g, s));
     const int t_hi = bucket_t_hi(g, seq_len);
     if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_step(g, with_logits, t_hi, s);
     if (g->graph_stream != s) ZG_TRY(capture_all(g, s));  // the caller switched streams after zg_gpt_create
@@ -555,6 +580,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         return hip_fail(he, "hipHostMalloc(control mirrors)", __FILE__, __LINE__);
     }
     g->steps_enqueued = 0;
+    g->ln_folded = false;
     {   // every decode graph is captured and instantiated here, not on the first forward that needs it
         const int st = capture_all(g, ctx().stream);
         if (st != ZG_OK) {
@@ -605,6 +631,7 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
         default: ZG_REQUIRE(false, ZG_ERR_ARG, "unknown block slot %d", slot);
     }
     ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "block slot %d expects %zu elements, got %zu", slot, n, len);
+    g->ln_folded = false;
     ZG_TRY(upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream));
     if (mat && g->wt == WT_F32 && y.c_attn_p) {  // exact bf16 planes of the fp32 matrix for the whole-prompt GEMMs
         bf16_t* pl = slot == ZG_C_ATTN_W ? y.c_attn_p : slot == ZG_C_PROJ_W ? y.c_proj_p : slot == ZG_C_FC_W ? y.c_fc_p : y.mlp_proj_p;
@@ -841,6 +868,7 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
                "profile_step: positions %zu..%zu outside the context", seq_len, seq_len + iters - 1);
     hipStream_t s = ctx().stream;
     ZG_HIP(hipStreamSynchronize(s));
+    ZG_TRY(ensure_ln_folded(g, s));
     for (size_t b = 0; b < g->batch; ++b) g->h_ints[b] = (int)(b % g->cfg.vocab_size);
     g->h_ctrl->step = (int)seq_len - 1;
     g->h_ctrl->seq_len = (int)seq_len;
@@ -887,6 +915,7 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     // control block: a mid-context position so that the attention kernel has work
     const size_t T = g->cfg.context_size / 2 > 0 ? g->cfg.context_size / 2 : 1;
     ZG_HIP(hipStreamSynchronize(s));
+    ZG_TRY(ensure_ln_folded(g, s));
     g->h_ctrl->step = (int)T - 1;
     g->h_ctrl->seq_len = (int)T;
     g->h_ctrl->mode = 1;

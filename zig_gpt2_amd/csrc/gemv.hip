@@ -737,6 +737,159 @@ bool gemv_use_ksplit(const GemvArgs& a) {
     return a.K >= min_k && a.K % 32 == 0 && a.K / 32 <= 256;
 }
 
+// ================================================================================================
+// M == 1, LayerNorm in front (ln_1 + c_attn, ln_2 + c_fc): the LayerNorm is LINEARISED out of the dot product.
+//
+//   y_n = sum_k W_nk ((x_k - mu) r g_k + b_k) + bias_n  =  r (S1_n - mu c2_n) + c3_n
+//   S1_n = sum_k W_nk (g_k x_k),   c2_n = sum_k W_nk g_k,   c3_n = sum_k W_nk b_k + bias_n
+//
+// c2 / c3 depend on the weights only (launch_ln_fold, once after loading); S1 needs no statistics, so the kernel
+// has the shape of the K-split kernel above — every load issued at entry, wave w owns K quarter w, FMAs straight
+// from registers — and mu, r (single pass sum / sum of squares, std = sqrt(E[x^2] - mean^2 + eps): ops.zig:88-101)
+// are needed only by the one thread per row that combines the four partial sums.  The kernel it replaces spent a
+// third of its time in the dependent chain load x -> two wave reductions -> normalise -> LDS -> registers before
+// its first FMA.  (Same real-number result; in floating point r (S1 - mu c2) cancels when |mu| >> sigma, which costs
+// log2(|mu| / sigma) bits of the fp32 product sums — far inside the 1e-3 bound for any LayerNorm input.)
+template <typename WT, int LPR, int CPL>
+__global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N, int K,
+                                                       int epilogue, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ c2, const float* __restrict__ c3,
+                                                       const GemvArgs a) {
+    __shared__ float part[4][16];
+    __shared__ float stat[4][2];
+    constexpr int RPP = 64 / LPR, ROWS = 2 * RPP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane % LPR, rsub = lane / LPR;
+    const int Kq = K >> 2, nchq = Kq >> 3;
+    const WT* W = reinterpret_cast<const WT*>(Wv) + (size_t)wave * Kq;
+    const int row0 = blockIdx.x * ROWS;
+    const int r0 = row0 + rsub, r1 = row0 + RPP + rsub;
+    Raw<WT> wa[CPL], wb[CPL];
+    {
+        const WT* p0 = W + (size_t)min(r0, N - 1) * K;
+        const WT* p1 = W + (size_t)min(r1, N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = min(lr + LPR * i, nchq - 1);
+            wa[i] = load_raw(p0, c);
+            wb[i] = load_raw(p1, c);
+        }
+    }
+    W8 xr[CPL], gr[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const size_t off = (size_t)wave * Kq + (size_t)min(lr + LPR * i, nchq - 1) * 8;
+        xr[i] = load_x8(xin + off);
+        gr[i] = load_x8(ln_g + off);
+    }
+    float c2n = 0.0f, c3n = 0.0f;
+    if (tid < ROWS) {
+        const int n = min(row0 + tid, N - 1);
+        c2n = c2[n];
+        c3n = c3[n];
+    }
+    const int T = a.ctrl ? a.ctrl->seq_len : 1;  // KV append position (EPI_QKV)
+    // statistics of this wave's quarter (every LPR-lane group holds the whole quarter) and z = g x
+    float sx = 0.0f, sxx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        if (lr + LPR * i >= nchq) xr[i] = zero_w8();  // clamped surplus chunks contribute nothing
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sx += xr[i].v[j];
+            sxx = fmaf(xr[i].v[j], xr[i].v[j], sxx);
+            xr[i].v[j] *= gr[i].v[j];
+        }
+    }
+    sx = group_allsum<LPR>(sx);
+    sxx = group_allsum<LPR>(sxx);
+    auto dot = [&](const Raw<WT>(&w)[CPL]) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const W8 u = unpack(w[i]);
+            p0 = fmaf(u.v[0], xr[i].v[0], p0); p1 = fmaf(u.v[1], xr[i].v[1], p1);
+            p2 = fmaf(u.v[2], xr[i].v[2], p2); p3 = fmaf(u.v[3], xr[i].v[3], p3);
+            p0 = fmaf(u.v[4], xr[i].v[4], p0); p1 = fmaf(u.v[5], xr[i].v[5], p1);
+            p2 = fmaf(u.v[6], xr[i].v[6], p2); p3 = fmaf(u.v[7], xr[i].v[7], p3);
+        }
+        return group_allsum<LPR>((p0 + p1) + (p2 + p3));
+    };
+    const float s0 = dot(wa), s1 = dot(wb);
+    if (lr == 0) {
+        part[wave][rsub] = s0;
+        part[wave][RPP + rsub] = s1;
+    }
+    if (lane == 0) {
+        stat[wave][0] = sx;
+        stat[wave][1] = sxx;
+    }
+    __syncthreads();
+    if (tid < ROWS && row0 + tid < N) {
+        const int n = row0 + tid;
+        const float inv_k = 1.0f / (float)K;
+        const float mean = ((stat[0][0] + stat[1][0]) + (stat[2][0] + stat[3][0])) * inv_k;
+        const float ex2 = ((stat[0][1] + stat[1][1]) + (stat[2][1] + stat[3][1])) * inv_k;
+        const float rstd = __builtin_amdgcn_rsqf(ex2 - mean * mean + a.eps);
+        const float S1 = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        const float y = fmaf(rstd, fmaf(-mean, c2n, S1), c3n);
+        Best nobest;
+        epilogue_row(a, 0, n, y, 0.0f, 0.0f, T - 1, nobest);
+    }
+}
+
+// c2[n] = sum_k W[n][k] g[k], c3[n] = sum_k W[n][k] b[k] + bias[n]: one wave per row, fp32 accumulation.
+template <typename WT>
+__global__ __launch_bounds__(256) void ln_fold_kernel(const void* __restrict__ Wv, const float* __restrict__ g,
+                                                      const float* __restrict__ b, const float* __restrict__ bias, int N, int K,
+                                                      float* __restrict__ c2, float* __restrict__ c3) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const WT* w = reinterpret_cast<const WT*>(Wv) + (size_t)row * K;
+    float s2 = 0.0f, s3 = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        float wv;
+        if constexpr (sizeof(WT) == 2) wv = __uint_as_float((uint32_t)w[k] << 16);
+        else wv = w[k];
+        s2 = fmaf(wv, g[k], s2);
+        s3 = fmaf(wv, b[k], s3);
+    }
+    s2 = wave_allsum(s2);
+    s3 = wave_allsum(s3);
+    if (lane == 0) {
+        c2[row] = s2;
+        c3[row] = s3 + (bias ? bias[row] : 0.0f);
+    }
+}
+
+template <typename WT>
+int launch_lnk(const GemvArgs& a, hipStream_t s) {
+    const int nchq = a.K / 32;
+#define ZG_LK(LPR_, CPL_)                                                                                              \
+    {                                                                                                                  \
+        constexpr int rows = 2 * (64 / LPR_);                                                                          \
+        hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
+                           a.N, a.K, a.epilogue, a.ln_g, a.ln_c2, a.ln_c3, a);                                         \
+        ZG_HIP(hipGetLastError());                                                                                     \
+        return ZG_OK;                                                                                                  \
+    }
+    if (nchq <= 16 * 2) ZG_LK(16, 2)
+    if (nchq <= 32 * 2) ZG_LK(32, 2)
+    if (nchq <= 32 * 3) ZG_LK(32, 3)
+    if (nchq <= 64 * 2) ZG_LK(64, 2)
+#undef ZG_LK
+    zg::set_error("gemv (LayerNorm, K split): K=%d too large", a.K);
+    return ZG_ERR_UNSUPPORTED;
+}
+
+bool gemv_use_lnk(const GemvArgs& a) {
+    static const int off = getenv("ZGPT2_NO_LNK") ? atoi(getenv("ZGPT2_NO_LNK")) : 0;
+    if (off || a.M != 1 || a.prologue != PRO_LAYERNORM || a.ln_c2 == nullptr || a.ln_c3 == nullptr) return false;
+    if (a.epilogue != EPI_STORE && a.epilogue != EPI_GELU && a.epilogue != EPI_QKV) return false;
+    return a.K % 32 == 0 && a.K / 32 <= 128 && a.N <= 16384;
+}
+
 // Slow generic fallback for K % 8 != 0 (op tier only): one wave per row, scalar loads.
 template <typename WT>
 __global__ __launch_bounds__(256) void gemv_generic_kernel(const GemvArgs a) {
@@ -1193,6 +1346,16 @@ int launch_wt(const GemvArgs& a, int grid, hipStream_t s) {
 
 }  // namespace
 
+int launch_ln_fold(const void* W, int weight_type, const float* g, const float* b, const float* bias, int N, int K, float* c2,
+                   float* c3, hipStream_t s) {
+    if (weight_type == WT_BF16)
+        hipLaunchKernelGGL((ln_fold_kernel<bf16_t>), dim3((N + 3) / 4), dim3(256), 0, s, W, g, b, bias, N, K, c2, c3);
+    else
+        hipLaunchKernelGGL((ln_fold_kernel<float>), dim3((N + 3) / 4), dim3(256), 0, s, W, g, b, bias, N, K, c2, c3);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int gemv_lanes_per_row(int K) {
     const int nch = K / 8;
     if (nch <= 16 * 8) return 16;
@@ -1290,6 +1453,7 @@ int gemv_plan(GemvArgs& a, int weight_type) {
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
     if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);
     if (gemv_use_ksplit(a)) return weight_type == WT_BF16 ? launch_ksplit<bf16_t>(a, s) : launch_ksplit<float>(a, s);
+    if (gemv_use_lnk(a)) return weight_type == WT_BF16 ? launch_lnk<bf16_t>(a, s) : launch_lnk<float>(a, s);
     if (a.M > 1 && valu_lds(valu_mt(a.M), a.K) > 160 * 1024 && splittable(a)) {
         const int g = row_group(a);
         for (int m0 = 0; m0 < a.M; m0 += g) {

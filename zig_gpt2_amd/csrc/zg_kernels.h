@@ -35,6 +35,10 @@ struct GemvArgs {
     const float* ln_g;
     const float* ln_b;
     float eps;
+    // PRO_LAYERNORM, M == 1: the LayerNorm folded out of the dot product (launch_ln_fold): c2[n] = sum_k W g,
+    // c3[n] = sum_k W b + bias[n]; null = use the kernel that normalises the input first
+    const float* ln_c2;
+    const float* ln_c3;
     // PRO_ATTN_MERGE input: partials [M][H][max_splits][kPartStride]
     const float* part;
     int n_heads, head_dim, max_splits;
@@ -71,6 +75,8 @@ bool gemv_supported(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int gemv_kslices(const GemvArgs& a);
+int launch_ln_fold(const void* W, int weight_type, const float* g, const float* b, const float* bias, int N, int K, float* c2,
+                   float* c3, hipStream_t s);
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ attention
