@@ -42,6 +42,7 @@ struct zg_gpt {
     size_t arena_bytes, weight_region_bytes;
     void *wte, *wpe;
     float *ln_f_g, *ln_f_b;
+    float *lm_c2, *lm_c3;  // ln_f folded out of lm_head (batched decode): wte g, wte b
     std::vector<zg_layer> layers;
     // state
     StepCtrl* ctrl;
@@ -94,6 +95,8 @@ void carve(zg_gpt* g, char* base) {
     g->wpe = P(C * E * wb);
     g->ln_f_g = (float*)P(E * 4);
     g->ln_f_b = (float*)P(E * 4);
+    g->lm_c2 = (float*)P(V * 4);
+    g->lm_c3 = (float*)P(V * 4);
     g->layers.resize(L);
     for (size_t l = 0; l < L; ++l) {
         zg_layer& y = g->layers[l];
@@ -219,6 +222,8 @@ int enqueue_lm_head(zg_gpt* g, hipStream_t s) {
     a.x_stride = (int)E;
     a.ln_g = g->ln_f_g;
     a.ln_b = g->ln_f_b;
+    a.ln_c2 = g->lm_c2;
+    a.ln_c3 = g->lm_c3;
     a.epilogue = EPI_ARGMAX;
     a.logits = g->logits;
     a.logits_stride = (int)V;
@@ -257,6 +262,7 @@ int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
         ZG_TRY(launch_ln_fold(y.c_attn_w, g->wt, y.ln_1_g, y.ln_1_b, y.c_attn_b, 3 * E, E, y.c_attn_c2, y.c_attn_c3, s));
         ZG_TRY(launch_ln_fold(y.c_fc_w, g->wt, y.ln_2_g, y.ln_2_b, y.c_fc_b, 4 * E, E, y.c_fc_c2, y.c_fc_c3, s));
     }
+    ZG_TRY(launch_ln_fold(g->wte, g->wt, g->ln_f_g, g->ln_f_b, nullptr, (int)g->cfg.vocab_size, E, g->lm_c2, g->lm_c3, s));
     g->ln_folded = true;
     return ZG_OK;
 }
@@ -657,6 +663,7 @@ int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len) {
         default: ZG_REQUIRE(false, ZG_ERR_ARG, "unknown slot %d", slot);
     }
     ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "slot %d expects %zu elements, got %zu", slot, n, len);
+    g->ln_folded = false;
     return upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream);
 }
 
@@ -726,6 +733,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
             g->h_ints[b * C + i] = (int)t;
         }
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(enqueue_prefill(g, n_tokens, compute_logits != 0, s));
     if (compute_logits) {  // ln_f + lm_head of each sequence's last position through the decode kernels
         ZG_HIP(hipMemcpy2DAsync(g->x, E * 4, g->pf_x + (n_tokens - 1) * E, n_tokens * E * 4, E * 4, B,

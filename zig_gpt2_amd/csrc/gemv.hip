@@ -1022,7 +1022,41 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     auto row_of = [&](int j) { return NW >= 8 ? (wave & 7) : wave + NW * j; };
 
     constexpr bool kHasLn = NW == 4 || NW * KS * 32 <= 2048;  // fused LayerNorm is dispatched only for K <= 2048
-    if (kHasLn && prologue == PRO_LAYERNORM) {
+    // LayerNorm folded out of the product (see gemv_lnk_kernel): the planes hold split(g x) — no statistics in front
+    // of the MFMAs, no barrier in the prologue — and the epilogue applies r_m (S1 - mu_m c2_n) + c3_n with the row
+    // statistics that were summed alongside.
+    // (not for the vocabulary-wide form: its per-tile c2 / c3 fetches cost more than the one prologue barrier saves)
+    const bool lin_ln = !ARGMAX && kHasLn && prologue == PRO_LAYERNORM && a.ln_c2 != nullptr;
+    if (lin_ln) {
+        f32x4 v[RPW][JT], g4[JT];
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+            const int ic = min(cidx[t], nq - 1);
+            g4[t] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                v[j][t] = reinterpret_cast<const f32x4*>(xin + (size_t)min(row_of(j), M - 1) * a.x_stride)[ic];
+        }
+        float* stat = red;  // [8 rows][PARTS][2]
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int m = row_of(j);
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < JT; ++t) {
+                if (cidx[t] >= c1 || m >= M) v[j][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                t1 += (v[j][t].x + v[j][t].y) + (v[j][t].z + v[j][t].w);
+                t2 = fmaf(v[j][t].x, v[j][t].x, fmaf(v[j][t].y, v[j][t].y, fmaf(v[j][t].z, v[j][t].z, fmaf(v[j][t].w, v[j][t].w, t2))));
+                if (cidx[t] < c1) store_split4(planes, S, m, cidx[t] * 4, v[j][t] * g4[t]);
+            }
+            t1 = wave_allsum(t1);
+            t2 = wave_allsum(t2);
+            if (lane == 0) {
+                stat[(m * PARTS + part) * 2] = t1;
+                stat[(m * PARTS + part) * 2 + 1] = t2;
+            }
+        }
+    } else if (kHasLn && prologue == PRO_LAYERNORM) {
         f32x4 v[RPW][JT], g4[JT], b4[JT];
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -1116,6 +1150,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
         best[r].idx = 0x7fffffff;
     }
     const int pos = T - 1;
+    float ln_mu[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ln_rs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (lin_ln && wave == 0) {  // rows m = 4 bq + r of this lane
+        const float inv_k = 1.0f / (float)K;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = (bq & 1) * 4 + r;  // lanes 32..63 duplicate rows 0..7
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) {
+                s1 += red[(m * PARTS + p) * 2];
+                s2 += red[(m * PARTS + p) * 2 + 1];
+            }
+            ln_mu[r] = s1 * inv_k;
+            ln_rs[r] = __builtin_amdgcn_rsqf(s2 * inv_k - ln_mu[r] * ln_mu[r] + a.eps);
+        }
+    }
     const size_t plane = (size_t)kMfmaRows * S;
     const char* arow = planes + (size_t)(lane & 7) * S + bq * 16;  // A fragment: batch row (lane & 15) & 7
     // [2 buffers][NW waves][64 lanes][4].  When the planes alone nearly fill the LDS (K = 3072: 148 KiB) and the
@@ -1193,7 +1243,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
             }
             if (run_epilogue && lane < 32 && n < N) {  // lanes 0..31 hold batch rows 0..7
                 const bool first = KSL == 1 && tile == tile_begin;
-                const float bias_n = first ? pre_bias : (a.bias ? a.bias[n] : 0.0f);
+                float bias_n = first ? pre_bias : (a.bias ? a.bias[n] : 0.0f);
+                if (lin_ln) {  // y = r_m (S1 - mu_m c2_n) + c3_n; c3 already holds the bias
+                    const float c2n = a.ln_c2[n], c3n = a.ln_c3[n];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum[r] = fmaf(ln_rs[r], fmaf(-ln_mu[r], c2n, sum[r]), c3n);
+                    bias_n = 0.0f;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = bq * 4 + r;
