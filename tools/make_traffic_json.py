@@ -1,41 +1,47 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.md + <tag>_kernel_stats.md -> profiles/lm_head_traffic.json
-(the HBM traffic per launch of bench.py's roofline kernel, corrected as MI355X_MICROARCH.md prescribes:
-FETCH_SIZE is reported in KB and must be doubled on gfx950, WRITE_SIZE is taken as reported).
+"""<dir>/<tag>_pmc_{FETCH,WRITE}_SIZE.md + <tag>_kernel_stats.md -> <dir>/traffic.json: HBM traffic per launch of every
+kernel class of the 124M single-prompt decode step, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KB
+and reports half of a wide coalesced read on gfx950: doubled; WRITE_SIZE as reported).  bench.py quotes the entry of
+its dominant class with this provenance.
 
 usage: python tools/make_traffic_json.py <dir with the md files> <tag>"""
 import json
-import re
 import sys
 
-KERNEL = "gemv_kernel<unsigned short, 1, 16, 6, true>"
+CLASSES = {  # bench.py kernel class -> kernel symbol (substring of the rocprof name) at 124M, one prompt, bf16 weights
+    "ln_1 + c_attn + KV append": "gemv_lnk_kernel<unsigned short, 16, 2>",
+    "attention (split-KV decode)": "attn_decode_kernel<float>",
+    "head merge + attn c_proj + residual": "gemv_kernel<unsigned short, 1, 16, 6, false>",
+    "ln_2 + c_fc + GELU": "gemv_lnk_kernel<unsigned short, 16, 2>",
+    "mlp c_proj + residual": "gemv_ksplit_kernel<unsigned short, 32, 3>",
+    "ln_f + lm_head + argmax": "gemv_kernel<unsigned short, 1, 16, 6, true>",
+}
+NOTE = {"gemv_lnk_kernel<unsigned short, 16, 2>": "kernel shared by c_attn (3.54 MB) and c_fc (4.72 MB): average of both"}
 
 
-def row(path, col):
+def row(path, sym, col):
     for line in open(path):
-        if KERNEL in line:
+        if sym in line:
             cells = [c.strip() for c in line.strip().strip("|").split("|")]
             return float(cells[col])
-    raise SystemExit(f"{KERNEL} not found in {path}")
+    raise SystemExit(f"{sym} not found in {path}")
 
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
-    fetch = row(f"{d}/{tag}_pmc_FETCH_SIZE.md", 3)
-    write = row(f"{d}/{tag}_pmc_WRITE_SIZE.md", 3)
-    us = row(f"{d}/{tag}_kernel_stats.md", 2)
-    out = {
-        "kernel": "gemv_kernel<bf16,M=1,LPR16,CPL6,ARGMAX> (ln_f + lm_head + argmax)",
-        "round_profile": tag,
-        "FETCH_SIZE_avg_KB": fetch,
-        "WRITE_SIZE_avg_KB": write,
-        "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
-        "correction": "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM "
-                      "section); WRITE_SIZE as reported; counters in KB",
-        "rocprof_avg_us": us,
-        "source": f"profiles/{tag}_pmc_FETCH_SIZE.md, profiles/{tag}_pmc_WRITE_SIZE.md, profiles/{tag}_kernel_stats.md",
-    }
-    json.dump(out, open(f"{d}/lm_head_traffic.json", "w"), indent=1)
+    out = {}
+    for cls, sym in CLASSES.items():
+        fetch = row(f"{d}/{tag}_pmc_FETCH_SIZE.md", sym, 3)
+        write = row(f"{d}/{tag}_pmc_WRITE_SIZE.md", sym, 3)
+        us = row(f"{d}/{tag}_kernel_stats.md", sym, 2)
+        out[cls] = {
+            "kernel": sym, "FETCH_SIZE_avg_KB": fetch, "WRITE_SIZE_avg_KB": write,
+            "bytes_per_launch": int(round((2 * fetch + write) * 1024)), "rocprof_avg_us_in_situ": us,
+            "source": f"profiles/{tag}_pmc_FETCH_SIZE.md + profiles/{tag}_pmc_WRITE_SIZE.md (rocprofv3 --pmc, separate passes, full "
+                      f"1024-position context, eager launches; FETCH_SIZE doubled per MI355X_MICROARCH.md, KB units)"
+                      + (f"; {NOTE[sym]}" if sym in NOTE else ""),
+        }
+    json.dump({"124M/1/bf16": out}, open(f"{d}/traffic.json", "w"), indent=1)
     print(json.dumps(out))
 
 
