@@ -649,7 +649,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 // meet in LDS after the arithmetic, where one thread per row runs the epilogue.
 template <typename WT, int LPR, int CPL>
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N,
-                                                          int K, int epilogue, const GemvArgs a) {
+                                                          int K, int epilogue, int merge_splits, const GemvArgs a) {
+    // merge_splits > 0 (attn c_proj): the input is the head merge of the attention partials — every lane combines
+    // the <= 4 split partials of ITS OWN 8-element chunks (a chunk lies inside one head), all loads issued with the
+    // weights; no shared strip, no barrier in front of the FMAs (the merge through an LDS strip cost 3.9 us per
+    // launch against 2.55 us for the plain K-split kernel).
     __shared__ float part[4][16];
     constexpr int RPP = 64 / LPR, ROWS = 2 * RPP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -672,8 +676,47 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
         }
     }
     W8 xr[CPL];
+    if (merge_splits > 0) {
+        constexpr int MAXS = 4;
+        const int nsplit = merge_splits;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) xr[i] = load_x8(xin + (size_t)wave * Kq + (size_t)min(lr + LPR * i, nchq - 1) * 8);
+        for (int i = 0; i < CPL; ++i) {
+            const int e0 = wave * Kq + min(lr + LPR * i, nchq - 1) * 8;
+            const int h = e0 >> 6, d0 = e0 & 63;  // head_dim 64
+            const float* p = a.part + ((size_t)h * a.max_splits) * kPartStride;
+            float ms[MAXS], ls[MAXS];
+            W8 o[MAXS];
+#pragma unroll
+            for (int sp = 0; sp < MAXS; ++sp) {  // branch-free: surplus splits re-read the last valid one, weight 0 below
+                const float* ps = p + min(sp, nsplit - 1) * kPartStride;
+                ms[sp] = ps[64];
+                ls[sp] = ps[65];
+                const float2 a0 = *reinterpret_cast<const float2*>(ps + d0), a1 = *reinterpret_cast<const float2*>(ps + d0 + 2);
+                const float2 a2 = *reinterpret_cast<const float2*>(ps + d0 + 4), a3 = *reinterpret_cast<const float2*>(ps + d0 + 6);
+                o[sp].v[0] = a0.x; o[sp].v[1] = a0.y; o[sp].v[2] = a1.x; o[sp].v[3] = a1.y;
+                o[sp].v[4] = a2.x; o[sp].v[5] = a2.y; o[sp].v[6] = a3.x; o[sp].v[7] = a3.y;
+            }
+#pragma unroll
+            for (int sp = 0; sp < MAXS; ++sp)
+                if (sp >= nsplit) ms[sp] = -1e30f;
+            const float mx = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
+            float l = 0.0f;
+            W8 r = zero_w8();
+#pragma unroll
+            for (int sp = 0; sp < MAXS; ++sp) {
+                const float w = __expf(ms[sp] - mx);
+                l = fmaf(w, ls[sp], l);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r.v[j] = fmaf(w, o[sp].v[j], r.v[j]);
+            }
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[i].v[j] = r.v[j] * inv;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) xr[i] = load_x8(xin + (size_t)wave * Kq + (size_t)min(lr + LPR * i, nchq - 1) * 8);
+    }
     float bias_n = 0.0f, resid_n = 0.0f;
     if (tid < ROWS) {
         const int n = min(row0 + tid, N - 1);
@@ -711,14 +754,16 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
 template <typename WT>
 int launch_ksplit(const GemvArgs& a, hipStream_t s) {
     const int nchq = a.K / 32;  // 16-B chunks per quarter row
+    const int merge_splits = a.prologue == PRO_ATTN_MERGE ? (a.t_hi + kAttnChunk - 1) / kAttnChunk : 0;
 #define ZG_KS(LPR_, CPL_)                                                                                                \
     {                                                                                                                    \
         constexpr int rows = 2 * (64 / LPR_);                                                                            \
         hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
-                           a.N, a.K, a.epilogue, a);                                                                     \
+                           a.N, a.K, a.epilogue, merge_splits, a);                                                       \
         ZG_HIP(hipGetLastError());                                                                                       \
         return ZG_OK;                                                                                                    \
     }
+    if (nchq <= 16 * 2) ZG_KS(16, 2)
     if (nchq <= 32 * 3) ZG_KS(32, 3)
     if (nchq <= 32 * 5) ZG_KS(32, 5)
     if (nchq <= 32 * 7) ZG_KS(32, 7)
@@ -732,8 +777,11 @@ int launch_ksplit(const GemvArgs& a, hipStream_t s) {
 bool gemv_use_ksplit(const GemvArgs& a) {
     static const int off = getenv("ZGPT2_NO_KSPLIT") ? atoi(getenv("ZGPT2_NO_KSPLIT")) : 0;
     static const int min_k = getenv("ZGPT2_KSPLIT_MIN_K") ? atoi(getenv("ZGPT2_KSPLIT_MIN_K")) : 2048;
-    if (off || a.M != 1 || a.prologue != PRO_NONE) return false;
+    if (off || a.M != 1) return false;
     if (a.epilogue != EPI_STORE && a.epilogue != EPI_RESIDUAL && a.epilogue != EPI_GELU) return false;
+    if (a.prologue == PRO_ATTN_MERGE)  // head merge folded into the lanes' own chunks: model tier, <= 4 splits known at launch
+        return a.head_dim == 64 && a.t_hi > 0 && (a.t_hi + kAttnChunk - 1) / kAttnChunk <= 4 && a.K % 32 == 0 && a.K <= 1024;  // wider rows (XL, K = 1600: three chunks per lane) measured slower than the shared strip
+    if (a.prologue != PRO_NONE) return false;
     return a.K >= min_k && a.K % 32 == 0 && a.K / 32 <= 256;
 }
 
