@@ -647,33 +647,28 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 // straight from global memory into registers (fetched next to the weights, no LDS, no barrier), every wave streams
 // the same 2 * RPP rows (quarter-row segments of >= 1.5 KB, fully coalesced), and the four partial sums per row
 // meet in LDS after the arithmetic, where one thread per row runs the epilogue.
-template <typename WT, int LPR, int CPL>
+template <typename WT, int LPR, int CPL, int NP = 2>  // NP passes of 64 / LPR rows per workgroup
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N,
                                                           int K, int epilogue, int merge_splits, const GemvArgs a) {
     // merge_splits > 0 (attn c_proj): the input is the head merge of the attention partials — every lane combines
     // the <= 4 split partials of ITS OWN 8-element chunks (a chunk lies inside one head), all loads issued with the
     // weights; no shared strip, no barrier in front of the FMAs (the merge through an LDS strip cost 3.9 us per
     // launch against 2.55 us for the plain K-split kernel).
-    __shared__ float part[4][16];
-    constexpr int RPP = 64 / LPR, ROWS = 2 * RPP;
+    constexpr int RPP = 64 / LPR, ROWS = NP * RPP;
+    __shared__ float part[4][ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane % LPR, rsub = lane / LPR;
     const int Kq = K >> 2, nchq = Kq >> 3;
     const WT* W = reinterpret_cast<const WT*>(Wv) + (size_t)wave * Kq;
     const int row0 = blockIdx.x * ROWS;
-    const int r0 = row0 + rsub, r1 = row0 + RPP + rsub;
-    // all loads of the kernel up front: two passes of weights, the input quarter, the epilogue operands
-    Raw<WT> wa[CPL], wb[CPL];
-    {
-        const WT* p0 = W + (size_t)min(r0, N - 1) * K;
-        const WT* p1 = W + (size_t)min(r1, N - 1) * K;
+    // all loads of the kernel up front: NP passes of weights, the input quarter, the epilogue operands
+    Raw<WT> wq[NP][CPL];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = min(lr + LPR * i, nchq - 1);
-            wa[i] = load_raw(p0, c);
-            wb[i] = load_raw(p1, c);
-        }
+    for (int p = 0; p < NP; ++p) {
+        const WT* pr = W + (size_t)min(row0 + p * RPP + rsub, N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) wq[p][i] = load_raw(pr, min(lr + LPR * i, nchq - 1));
     }
     W8 xr[CPL];
     if (merge_splits > 0) {
@@ -738,10 +733,12 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
         }
         return group_allsum<LPR>((p0 + p1) + (p2 + p3));
     };
-    const float s0 = dot(wa), s1 = dot(wb);
+    float sp[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) sp[p] = dot(wq[p]);
     if (lr == 0) {
-        part[wave][rsub] = s0;
-        part[wave][RPP + rsub] = s1;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) part[wave][p * RPP + rsub] = sp[p];
     }
     __syncthreads();
     if (tid < ROWS && row0 + tid < N) {
@@ -755,10 +752,11 @@ template <typename WT>
 int launch_ksplit(const GemvArgs& a, hipStream_t s) {
     const int nchq = a.K / 32;  // 16-B chunks per quarter row
     const int merge_splits = a.prologue == PRO_ATTN_MERGE ? (a.t_hi + kAttnChunk - 1) / kAttnChunk : 0;
+    // two passes of 64 / LPR rows per workgroup (four measured slower: 2.65 -> 3.3 us for mlp c_proj)
 #define ZG_KS(LPR_, CPL_)                                                                                                \
     {                                                                                                                    \
         constexpr int rows = 2 * (64 / LPR_);                                                                            \
-        hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
+        hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_, 2>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
                            a.N, a.K, a.epilogue, merge_splits, a);                                                       \
         ZG_HIP(hipGetLastError());                                                                                       \
         return ZG_OK;                                                                                                    \
@@ -798,31 +796,26 @@ bool gemv_use_ksplit(const GemvArgs& a) {
 // third of its time in the dependent chain load x -> two wave reductions -> normalise -> LDS -> registers before
 // its first FMA.  (Same real-number result; in floating point r (S1 - mu c2) cancels when |mu| >> sigma, which costs
 // log2(|mu| / sigma) bits of the fp32 product sums — far inside the 1e-3 bound for any LayerNorm input.)
-template <typename WT, int LPR, int CPL>
+template <typename WT, int LPR, int CPL, int NP = 2>  // NP passes of 64 / LPR rows per workgroup
 __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N, int K,
                                                        int epilogue, const float* __restrict__ ln_g,
                                                        const float* __restrict__ c2, const float* __restrict__ c3,
                                                        const GemvArgs a) {
-    __shared__ float part[4][16];
+    constexpr int RPP = 64 / LPR, ROWS = NP * RPP;
+    __shared__ float part[4][ROWS];
     __shared__ float stat[4][2];
-    constexpr int RPP = 64 / LPR, ROWS = 2 * RPP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane % LPR, rsub = lane / LPR;
     const int Kq = K >> 2, nchq = Kq >> 3;
     const WT* W = reinterpret_cast<const WT*>(Wv) + (size_t)wave * Kq;
     const int row0 = blockIdx.x * ROWS;
-    const int r0 = row0 + rsub, r1 = row0 + RPP + rsub;
-    Raw<WT> wa[CPL], wb[CPL];
-    {
-        const WT* p0 = W + (size_t)min(r0, N - 1) * K;
-        const WT* p1 = W + (size_t)min(r1, N - 1) * K;
+    Raw<WT> wq[NP][CPL];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = min(lr + LPR * i, nchq - 1);
-            wa[i] = load_raw(p0, c);
-            wb[i] = load_raw(p1, c);
-        }
+    for (int p = 0; p < NP; ++p) {
+        const WT* pr = W + (size_t)min(row0 + p * RPP + rsub, N - 1) * K;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) wq[p][i] = load_raw(pr, min(lr + LPR * i, nchq - 1));
     }
     W8 xr[CPL], gr[CPL];
 #pragma unroll
@@ -864,10 +857,12 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         }
         return group_allsum<LPR>((p0 + p1) + (p2 + p3));
     };
-    const float s0 = dot(wa), s1 = dot(wb);
+    float sp[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) sp[p] = dot(wq[p]);
     if (lr == 0) {
-        part[wave][rsub] = s0;
-        part[wave][RPP + rsub] = s1;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) part[wave][p * RPP + rsub] = sp[p];
     }
     if (lane == 0) {
         stat[wave][0] = sx;
@@ -914,10 +909,11 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const void* __restrict__ W
 template <typename WT>
 int launch_lnk(const GemvArgs& a, hipStream_t s) {
     const int nchq = a.K / 32;
+    // four passes of 64 / LPR rows per workgroup (2.93 against 3.2 us per launch with two; +1 % tokens/s in situ)
 #define ZG_LK(LPR_, CPL_)                                                                                              \
     {                                                                                                                  \
-        constexpr int rows = 2 * (64 / LPR_);                                                                          \
-        hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
+        constexpr int rows = 4 * (64 / LPR_);                                                                          \
+        hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_, 4>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
                            a.N, a.K, a.epilogue, a.ln_g, a.ln_c2, a.ln_c3, a);                                         \
         ZG_HIP(hipGetLastError());                                                                                     \
         return ZG_OK;                                                                                                  \
