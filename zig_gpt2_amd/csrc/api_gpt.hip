@@ -921,7 +921,11 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     const size_t E = g->cfg.n_embed, wb = g->wbytes;
     const size_t bytes_tab[7] = {0, 3 * E * E * wb, 0, E * E * wb, 4 * E * E * wb, 4 * E * E * wb, g->cfg.vocab_size * E * wb};
     // control block: a mid-context position so that the attention kernel has work
-    const size_t T = g->cfg.context_size / 2 > 0 ? g->cfg.context_size / 2 : 1;
+    size_t T = g->cfg.context_size / 2 > 0 ? g->cfg.context_size / 2 : 1;
+    if (const char* e = getenv("ZGPT2_TIME_T")) {  // measurement: another position for the attention kernel
+        const long v = atol(e);
+        if (v >= 1 && (size_t)v <= g->cfg.context_size) T = (size_t)v;
+    }
     ZG_HIP(hipStreamSynchronize(s));
     ZG_TRY(ensure_ln_folded(g, s));
     g->h_ctrl->step = (int)T - 1;
