@@ -1,0 +1,176 @@
+// Feasibility probe (development tool, not part of the library): what does one all-to-all hand-off between two
+// dependent M = 1 Linear kernels cost when the consumer is ALREADY RESIDENT — launched on a second stream, its
+// weights in registers — and waits on the data itself (every element travels as a {value, tag} pair written with
+// agent-scope stores, the consumer polls until all its tags match) instead of on a kernel boundary?
+//
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/handoff_probe tools/handoff_probe.hip && /tmp/handoff_probe
+//
+// A "step" is a chain of L stages y <- W_k y (N = K, bf16 weights, fp32 pairs) replayed as a hipGraph:
+//   mode 0: one stream, plain loads, no tags            (today's design: launch boundary per stage)
+//   mode 1: one stream, tagged pairs                     (cost of the tagging alone)
+//   mode 2: S streams round robin, tagged pairs          (S kernels in flight, data-driven hand-off)
+// Every poll loop is bounded; a timeout sets ctrl->err and the stage proceeds, so a bug cannot hang the GPU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Ctrl { unsigned seq; unsigned err; unsigned spins; unsigned pad; };
+typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float bf(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__global__ void begin_kernel(Ctrl* c, u64* vec, int K) {
+    // join node: bumps the sequence number and publishes the step's input with tag seq * 256
+    unsigned s = c->seq + 1;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        float v = 0.25f + 0.001f * (float)(i % 17);
+        __hip_atomic_store(vec + i, ((u64)(s * 256u) << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) c->seq = s;
+}
+
+__global__ void end_kernel(Ctrl* c, const u64* vec, float* out, int K) {
+    for (int i = threadIdx.x; i < K; i += blockDim.x) out[i] = __uint_as_float((unsigned)vec[i]);
+}
+
+// One stage: out[n] = scale * sum_k W[n][k] in[k].  256 threads = 4 waves, each wave one K quarter; lane = (row r of
+// 16, part q of 4).  KQ = K / 16 elements per lane.  TAGGED: in / out are {value, tag} pairs.
+template <int KQ, int QL, bool TAGGED>
+__global__ __launch_bounds__(256) void stage_kernel(const unsigned short* __restrict__ W, const u64* in, u64* out, const float* fin,
+                                                    float* fout, Ctrl* c, int K, int stage) {
+    constexpr int RW = 64 / QL;  // rows per workgroup
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane / QL, q = lane % QL;
+    const int row = blockIdx.x * RW + r;
+    const int kb = (w * QL + q) * KQ;
+    __shared__ float part[4][16];
+    u32x4 wr[KQ / 8];
+#pragma unroll
+    for (int i = 0; i < KQ / 8; ++i) wr[i] = __builtin_nontemporal_load((const u32x4*)(W + (size_t)row * K + kb) + i);
+    float x[KQ];
+    if (TAGGED) {
+        const unsigned seq = __hip_atomic_load(&c->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = seq * 256u + (unsigned)stage;
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+            u64 p[KQ];
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) p[i] = __hip_atomic_load(in + kb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                ok &= (unsigned)(p[i] >> 32) == want;
+                x[i] = __uint_as_float((unsigned)p[i]);
+            }
+            if (!ok) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 18)) { c->err = 1000u + (unsigned)stage; break; }
+            }
+        } while (!ok);
+        if (spins && lane == 0 && w == 0 && blockIdx.x == 0) c->spins += spins;
+    } else {
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) x[i] = fin[kb + i];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < KQ / 8; ++i) {
+        const unsigned u[4] = {wr[i].x, wr[i].y, wr[i].z, wr[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc += bf((unsigned short)(u[j] & 0xffff)) * x[i * 8 + 2 * j];
+            acc += bf((unsigned short)(u[j] >> 16)) * x[i * 8 + 2 * j + 1];
+        }
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (QL == 8) acc += __shfl_xor(acc, 4);
+    if (q == 0) part[w][r] = acc;
+    __syncthreads();
+    if (threadIdx.x < RW) {
+        const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        const int n = blockIdx.x * RW + threadIdx.x;
+        if (TAGGED) {
+            const unsigned seq = __hip_atomic_load(&c->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(out + n, ((u64)(seq * 256u + (unsigned)stage + 1u) << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            fout[n] = v;
+        }
+    }
+}
+
+template <int KQ, int QL>
+static void launch_stage(bool tagged, hipStream_t s, int G, const unsigned short* W, const u64* in, u64* out, const float* fin, float* fout,
+                         Ctrl* c, int K, int stage) {
+    if (tagged) hipLaunchKernelGGL((stage_kernel<KQ, QL, true>), dim3(G), dim3(256), 0, s, W, in, out, fin, fout, c, K, stage);
+    else hipLaunchKernelGGL((stage_kernel<KQ, QL, false>), dim3(G), dim3(256), 0, s, W, in, out, fin, fout, c, K, stage);
+}
+
+int main(int argc, char** argv) {
+    const int L = 60, R = 200;
+    CK(hipSetDevice(0));
+    for (int K : {768, 1536}) {
+        const int N = K, G = K == 768 ? N / 16 : N / 8;
+        std::vector<unsigned short> hw((size_t)N * K);
+        // rows that keep the vector bounded: every row sums to about 1 (bf16 of 1/K)
+        unsigned bits; float inv = 1.0f / (float)K; memcpy(&bits, &inv, 4);
+        for (auto& v : hw) v = (unsigned short)(bits >> 16);
+        unsigned short* W; CK(hipMalloc(&W, (size_t)L * N * K * 2));
+        for (int l = 0; l < L; ++l) CK(hipMemcpy(W + (size_t)l * N * K, hw.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+        u64* vec[2]; float* fvec[2]; Ctrl* c; float* out;
+        for (int i = 0; i < 2; ++i) { CK(hipMalloc(&vec[i], K * 8)); CK(hipMemset(vec[i], 0, K * 8)); CK(hipMalloc(&fvec[i], K * 4)); CK(hipMemset(fvec[i], 0, K * 4)); }
+        CK(hipMalloc(&c, sizeof(Ctrl))); CK(hipMemset(c, 0, sizeof(Ctrl))); CK(hipMalloc(&out, K * 4));
+        for (int mode = 0; mode <= 4; ++mode) {
+            const int S = mode <= 1 ? 1 : mode;  // streams
+            const bool tagged = mode >= 1;
+            hipStream_t st[4]; hipEvent_t fork, join[4];
+            for (int i = 0; i < S; ++i) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+            CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+            for (int i = 0; i < S; ++i) CK(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeGlobal));
+            hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(256), 0, st[0], c, vec[0], K);
+            CK(hipEventRecord(fork, st[0]));
+            for (int i = 1; i < S; ++i) CK(hipStreamWaitEvent(st[i], fork, 0));
+            for (int k = 0; k < L; ++k) {
+                hipStream_t s = st[k % S];
+                const unsigned short* Wk = W + (size_t)k * N * K;
+                if (K == 768) launch_stage<48, 4>(tagged, s, G, Wk, vec[k & 1], vec[(k + 1) & 1], fvec[k & 1], fvec[(k + 1) & 1], c, K, k);
+                else launch_stage<48, 8>(tagged, s, G, Wk, vec[k & 1], vec[(k + 1) & 1], fvec[k & 1], fvec[(k + 1) & 1], c, K, k);
+            }
+            for (int i = 1; i < S; ++i) { CK(hipEventRecord(join[i], st[i])); CK(hipStreamWaitEvent(st[0], join[i], 0)); }
+            hipLaunchKernelGGL(end_kernel, dim3(1), dim3(256), 0, st[0], c, vec[L & 1], out, K);
+            CK(hipStreamEndCapture(st[0], &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge, st[0]));
+            CK(hipStreamSynchronize(st[0]));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, st[0]));
+                for (int i = 0; i < R; ++i) CK(hipGraphLaunch(ge, st[0]));
+                CK(hipEventRecord(e1, st[0]));
+                CK(hipStreamSynchronize(st[0]));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            Ctrl hc; CK(hipMemcpy(&hc, c, sizeof(Ctrl), hipMemcpyDeviceToHost));
+            std::vector<float> ho(K); CK(hipMemcpy(ho.data(), out, K * 4, hipMemcpyDeviceToHost));
+            printf("{\"K\": %d, \"mode\": %d, \"streams\": %d, \"tagged\": %d, \"us_per_stage\": %.3f, \"us_per_step\": %.1f, \"err\": %u, \"spins\": %u, \"out0\": %g}\n",
+                   K, mode, S, (int)tagged, best * 1e3f / (R * (L + 2)), best * 1e3f / R, hc.err, hc.spins, tagged ? ho[0] : 0.f);
+            fflush(stdout);
+            CK(hipMemset(&c->err, 0, 8));  // seq keeps counting: tags never repeat
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            for (int i = 0; i < S; ++i) CK(hipStreamDestroy(st[i]));
+        }
+        CK(hipFree(W));
+    }
+    return 0;
+}
