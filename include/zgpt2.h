@@ -154,9 +154,11 @@ enum {
     ZG_GPT_NO_GRAPH = 1 << 1,    /* launch kernels eagerly instead of replaying a hipGraph */
     ZG_GPT_KV_F16 = 1 << 2,      /* store the KV cache as fp16 instead of fp32 */
     ZG_GPT_NO_PREFILL = 1 << 3,  /* generate: feed prompts one position at a time, as main.zig:331-334 does */
-    ZG_GPT_PREFILL_2PLANE = 1 << 4 /* whole-prompt GEMMs multiply two bf16 planes of the fp32 activations instead of the exact
+    ZG_GPT_PREFILL_2PLANE = 1 << 4, /* whole-prompt GEMMs multiply two bf16 planes of the fp32 activations instead of the exact
                                       three: 2/3 of the matrix work, ~2e-5 of the logit scale (inside the 1e-3 parity bound,
                                       outside the tests' near-zero floor); bf16-weight handles only */
+    ZG_GPT_NO_PREFETCH = 1 << 5  /* zg_gpt_generate_*: no side-stream L2 prefetcher beside the decode chain (results are
+                                    identical either way; a measurement switch) */
 };
 
 /* Per-block tensor slots (load_block, src/main.zig:271-302) and top-level slots (load_gpt,
@@ -245,6 +247,13 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
  *       boundary + event overhead contained in every interval above.
  * Intervals are event-to-event, so each includes the boundary to the next kernel. */
 int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, size_t n_out);
+
+/* Diagnostic: how the side-stream prefetcher of the last zg_gpt_generate_* call ended (waits for both streams).
+ * out[0] = 1 when the handle has a prefetcher (2: it found no concurrency with the decode stream once and is no longer
+ * launched); then per XCD x = 0..7: out[1 + x] prefetcher workgroups that ran
+ * there, out[9 + x] why they left (1 = stop behind the last step, 2 = progress stalled), out[17 + x] launches they
+ * fetched for.  n_out >= 25.  No reference counterpart. */
+int zg_debug_prefetch_stats(zg_gpt* g, unsigned* out, size_t n_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Tokenizer — src/bpe.zig (host side).  Encoder.init takes the two JSON objects of

@@ -71,6 +71,7 @@ SIGNATURES = {
     "zg_gpt_generate_fetch": (C.c_int, [vp, sz, vp, sz]),
     "zg_gpt_time_kernel": (C.c_int, [vp, C.c_int, C.c_int, f32p, szp]),
     "zg_gpt_profile_step": (C.c_int, [vp, sz, C.c_int, f32p, sz]),
+    "zg_debug_prefetch_stats": (C.c_int, [vp, vp, sz]),
     "zg_bpe_create": (C.c_int, [C.POINTER(vp), vp, vp, sz, vp, vp, sz]),
     "zg_bpe_destroy": (C.c_int, [vp]),
     "zg_bpe_encode": (C.c_int, [vp, C.c_char_p, sz, vp, sz, szp]),
@@ -78,7 +79,7 @@ SIGNATURES = {
 }
 
 # flags / slots of include/zgpt2.h
-GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL, GPT_PREFILL_2PLANE = 0, 1, 2, 4, 8, 16
+GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL, GPT_PREFILL_2PLANE, GPT_NO_PREFETCH = 0, 1, 2, 4, 8, 16, 32
 BLOCK_SLOTS = ["ln_1_g", "ln_1_b", "c_attn_w", "c_attn_b", "c_proj_w", "c_proj_b",
                "ln_2_g", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b"]
 TOP_SLOTS = ["wte", "wpe", "ln_f_g", "ln_f_b"]

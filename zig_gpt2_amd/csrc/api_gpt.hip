@@ -67,6 +67,15 @@ struct zg_gpt {
     hipStream_t graph_stream;
     size_t steps_enqueued;
     bool ln_folded;  // c2 / c3 of every layer match the weights currently in the arena
+    // side-stream L2 prefetcher of the decode chain (prefetch.hip); runs during zg_gpt_generate_enqueue only
+    PfCtl* pf_ctl;
+    PfJob* pf_jobs;  // [pf_njobs]: embed, 5 per layer, lm_head
+    int pf_njobs;
+    bool pf_on;
+    bool pf_ran;      // a prefetcher was launched by the last generate call
+    bool pf_stalled;  // one left on its idle limit (no concurrency with the decode stream here): not launched again
+    hipStream_t pf_stream;
+    hipEvent_t pf_ev_main, pf_ev_side;
 };
 
 namespace {
@@ -145,6 +154,9 @@ void carve(zg_gpt* g, char* base) {
     g->sk_tiles = (int)((E + 15) / 16);
     g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
     g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4);
+    g->pf_njobs = (int)(2 + 5 * L);
+    g->pf_ctl = (PfCtl*)P(sizeof(PfCtl));
+    g->pf_jobs = (PfJob*)P((size_t)g->pf_njobs * sizeof(PfJob));
     g->pf_x = g->pf_qkv = g->pf_ws = nullptr;
     g->pf_a = g->pf_h = nullptr;
     g->pf_ws_floats = 0;
@@ -185,6 +197,7 @@ GemvArgs base_gemv(const zg_gpt* g, const void* W, const float* bias, size_t N, 
     a.sk_ws = g->sk_ws;
     a.sk_cnt = g->sk_cnt;
     a.sk_tiles = g->sk_tiles;
+    a.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
     return a;
 }
 
@@ -210,10 +223,42 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.n_partials = g->lm_grid;
     e.x = g->x;
     e.finish_only = finish_only;
+    e.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
     return e;
 }
 
-int enqueue_lm_head(zg_gpt* g, hipStream_t s) {
+// A planned decode launch: enqueue it, or (rec != nullptr: building the prefetcher's job table at create) describe
+// the weight tiles its workgroups read.
+int emit_gemv(const zg_gpt* g, const GemvArgs& a, int grid, hipStream_t s, std::vector<PfJob>* rec, unsigned cls) {
+    if (!rec) return launch_gemv(a, g->wt, grid, s);
+    PfJob j{};
+    j.cls = cls;
+    const int rows = gemv_rows_per_wg(a, g->wt);
+    if (rows > 0) {
+        j.kind = PF_WEIGHTS;
+        j.base = reinterpret_cast<const char*>(a.W);
+        j.total_bytes = (size_t)a.N * a.K * g->wbytes;
+        j.wg_bytes = (unsigned)((size_t)rows * a.K * g->wbytes);
+        j.n_wg = (unsigned)grid;
+        j.touch_bytes = j.wg_bytes;
+        if (a.M == 1) {
+            const bool lnk = a.prologue == PRO_LAYERNORM && a.ln_c2 != nullptr;
+            const float* v[3] = {lnk ? a.ln_g : nullptr, lnk ? a.ln_c2 : a.bias, lnk ? a.ln_c3 : nullptr};
+            const size_t n[3] = {(size_t)a.K * 4, (size_t)a.N * 4, (size_t)a.N * 4};
+            for (int i = 0; i < 3; ++i) {
+                j.aux[i] = reinterpret_cast<const char*>(v[i]);
+                j.aux_bytes[i] = v[i] ? (unsigned)n[i] : 0u;
+            }
+        }
+        // a matrix far larger than the L2s (lm_head): only the head of every tile, about 16 MiB in all
+        const size_t cap = (size_t)16 << 20;
+        if (j.total_bytes > cap) j.touch_bytes = (unsigned)(((size_t)j.wg_bytes * cap / j.total_bytes + 127) & ~(size_t)127);
+    }
+    rec->push_back(j);
+    return ZG_OK;
+}
+
+int enqueue_lm_head(zg_gpt* g, hipStream_t s, std::vector<PfJob>* rec = nullptr) {
     const size_t E = g->cfg.n_embed, V = g->cfg.vocab_size;
     // ln_f (main.zig:189) + lm_head = wte, no bias (main.zig:192-194, :312) + greedy partial argmax
     GemvArgs a = base_gemv(g, g->wte, nullptr, V, E, 0);
@@ -231,7 +276,7 @@ int enqueue_lm_head(zg_gpt* g, hipStream_t s) {
     a.part_idx = g->part_idx;
     const int grid = gemv_plan(a, g->wt);
     ZG_REQUIRE(grid == g->lm_grid, ZG_ERR_ARG, "lm_head grid changed");
-    return launch_gemv(a, g->wt, grid, s);
+    return emit_gemv(g, a, grid, s, rec, 6);
 }
 
 // Optional per-kernel event recorder (zg_gpt_profile_step only).
@@ -268,13 +313,16 @@ int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
 }
 
 // One decode step = GPT.forward (main.zig:178-195) for all sequences.
-// `only` >= 0 (measurement): launch just that kernel class of layer 0.
-int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1) {
+// `only` >= 0 (measurement): launch just that kernel class of layer `only_layer`.
+// rec != nullptr: nothing is launched; the step's launches are described for the prefetcher instead (emit_gemv).
+int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1, size_t only_layer = 0,
+                 std::vector<PfJob>* rec = nullptr) {
     const size_t E = g->cfg.n_embed;
     ZG_TRY(prof_mark(prof, -1, s));
-    if (only < 0 || only == 0) ZG_TRY(launch_embed_step(embed_args(g, only == 0 ? 3 : 0), s));  // main.zig:179-183
+    if (rec) rec->push_back(PfJob{});
+    else if (only < 0 || only == 0) ZG_TRY(launch_embed_step(embed_args(g, only == 0 ? 3 : 0), s));  // main.zig:179-183
     ZG_TRY(prof_mark(prof, 0, s));
-    for (size_t l = 0; l < (only < 0 ? g->cfg.n_layer : 1); ++l) {
+    for (size_t l = (only < 0 ? 0 : only_layer); l < (only < 0 ? g->cfg.n_layer : only_layer + 1); ++l) {
         const zg_layer& y = g->layers[l];
         if (only < 0 || only == 1) {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
             GemvArgs a = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * E, E, t_hi);
@@ -290,7 +338,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.k_cache = y.k_cache;
             a.v_cache = y.v_cache;
             const int grid = gemv_plan(a, g->wt);
-            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(emit_gemv(g, a, grid, s, rec, 1));
             ZG_TRY(prof_mark(prof, 1, s));
         }
         if (only < 0 || only == 2) {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
@@ -309,7 +357,20 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.t_hi = t_hi;
             a.max_splits = g->max_splits;
             a.part = g->part;
-            ZG_TRY(launch_attn_decode(a, s));
+            a.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
+            if (rec) {  // the K and V rows of earlier positions, laid out for this grid
+                PfJob j{};
+                j.kind = PF_KV;
+                j.cls = 2;
+                j.base = reinterpret_cast<const char*>(y.k_cache);
+                j.base2 = reinterpret_cast<const char*>(y.v_cache);
+                j.n_heads = (unsigned)g->cfg.n_heads;
+                j.ctx = (unsigned)g->cfg.context_size;
+                j.batch = (unsigned)g->batch;
+                j.row_bytes = g->kv_f16 ? 128u : 256u;
+                rec->push_back(j);
+            } else
+                ZG_TRY(launch_attn_decode(a, s));
             ZG_TRY(prof_mark(prof, 2, s));
         }
         if (only < 0 || only == 3) {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
@@ -322,7 +383,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.resid = g->x;
             a.resid_stride = (int)E;
             const int grid = gemv_plan(a, g->wt);
-            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(emit_gemv(g, a, grid, s, rec, 3));
             ZG_TRY(prof_mark(prof, 3, s));
         }
         if (only < 0 || only == 4) {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
@@ -338,7 +399,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y = g->h4;
             a.y_stride = (int)(4 * E);
             const int grid = gemv_plan(a, g->wt);
-            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(emit_gemv(g, a, grid, s, rec, 4));
             ZG_TRY(prof_mark(prof, 4, s));
         }
         if (only < 0 || only == 5) {   // mlp c_proj + residual: main.zig:81, :142-145
@@ -352,12 +413,12 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.resid = g->x;
             a.resid_stride = (int)E;
             const int grid = gemv_plan(a, g->wt);
-            ZG_TRY(launch_gemv(a, g->wt, grid, s));
+            ZG_TRY(emit_gemv(g, a, grid, s, rec, 5));
             ZG_TRY(prof_mark(prof, 5, s));
         }
     }
     if (with_logits && (only < 0 || only == 6)) {
-        ZG_TRY(enqueue_lm_head(g, s));
+        ZG_TRY(enqueue_lm_head(g, s, rec));
         ZG_TRY(prof_mark(prof, 6, s));
     }
     return ZG_OK;
@@ -431,6 +492,96 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws,
                                    g->pf_ws_floats, more ? &ln1 : nullptr, s, nullptr, np));
     }
+    return ZG_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Side-stream prefetcher (prefetch.hip): job table, control block, low-priority stream.  Called from zg_gpt_create
+// BEFORE the graphs are captured (the decode kernels get the progress counter as an argument).
+int setup_prefetcher(zg_gpt* g) {
+    g->pf_on = g->pf_ran = g->pf_stalled = false;
+    g->pf_stream = nullptr;
+    g->pf_ev_main = g->pf_ev_side = nullptr;
+    // Default: only where it was measured to pay — one sequence and Linears of a few MB (GPT-2 124M: 241 -> 224 us per
+    // token; GPT-2 XL's 20 MB matrices cannot be fetched a launch ahead, 8 prompts gain < 1 %).  ZGPT2_PREFETCH=1 / 0 forces.
+    const bool small = g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
+    const int want = env_int("ZGPT2_PREFETCH", small ? 1 : 0);
+    if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || ctx().stream == nullptr) return ZG_OK;
+    std::vector<PfJob> jobs;
+    ZG_TRY(enqueue_step(g, true, (int)g->cfg.context_size, nullptr, nullptr, -1, 0, &jobs));
+    ZG_REQUIRE((int)jobs.size() == g->pf_njobs && g->pf_njobs <= 255, ZG_ERR_ARG, "prefetcher: %zu launches per step", jobs.size());
+    ZG_HIP(hipMemcpy(g->pf_jobs, jobs.data(), jobs.size() * sizeof(PfJob), hipMemcpyHostToDevice));
+    int least = 0, greatest = 0;
+    ZG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    ZG_HIP(hipStreamCreateWithPriority(&g->pf_stream, hipStreamNonBlocking, least));
+    ZG_HIP(hipEventCreateWithFlags(&g->pf_ev_main, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&g->pf_ev_side, hipEventDisableTiming));
+    g->pf_on = true;
+    return ZG_OK;
+}
+
+void drop_prefetcher(zg_gpt* g) {
+    if (g->pf_stream) {
+        (void)hipStreamSynchronize(g->pf_stream);
+        (void)hipStreamDestroy(g->pf_stream);
+    }
+    if (g->pf_ev_main) (void)hipEventDestroy(g->pf_ev_main);
+    if (g->pf_ev_side) (void)hipEventDestroy(g->pf_ev_side);
+    g->pf_stream = nullptr;
+    g->pf_ev_main = g->pf_ev_side = nullptr;
+    g->pf_on = false;
+}
+
+// Start the prefetcher for a run of decode steps ending at sequence length last_T: the control block is cleared on
+// the side stream (behind the previous run's prefetcher), the decode stream waits for that, and the prefetcher
+// starts once the decode stream reaches this point.  pf_stop() goes behind the last step.
+int pf_start(zg_gpt* g, size_t last_T, hipStream_t s) {
+    if (!g->pf_on || s == nullptr) return ZG_OK;
+    const int mode = env_int("ZGPT2_PF_MODE", 0);  // measurement: 1 = follow the chain but fetch nothing, 2 = count only
+    if (mode == 2) return ZG_OK;
+    if (g->pf_ran) {  // how did the previous one leave?  (the decode stream was synchronised by the caller)
+        ZG_HIP(hipStreamSynchronize(g->pf_stream));
+        unsigned why[8];
+        ZG_HIP(hipMemcpy(why, g->pf_ctl->exit_reason, sizeof(why), hipMemcpyDeviceToHost));
+        for (unsigned w : why) g->pf_stalled |= w == 2u;
+        g->pf_ran = false;
+    }
+    if (g->pf_stalled) return ZG_OK;
+    ZG_HIP(hipMemsetAsync(g->pf_ctl, 0, sizeof(PfCtl), g->pf_stream));
+    ZG_HIP(hipEventRecord(g->pf_ev_side, g->pf_stream));
+    ZG_HIP(hipStreamWaitEvent(s, g->pf_ev_side, 0));
+    ZG_HIP(hipEventRecord(g->pf_ev_main, s));
+    ZG_HIP(hipStreamWaitEvent(g->pf_stream, g->pf_ev_main, 0));
+    PfArgs a{};
+    a.ctl = g->pf_ctl;
+    a.jobs = g->pf_jobs;
+    a.njobs = g->pf_njobs;
+    a.lead = env_int("ZGPT2_PF_LEAD", 2);
+    a.nsub = env_int("ZGPT2_PF_NSUB", 12);
+    a.max_T = (int)last_T;
+    a.idle_limit = (unsigned)env_int("ZGPT2_PF_IDLE", 100000);  // polls without progress (~0.1 s) before it gives up
+    a.sleep = (unsigned)env_int("ZGPT2_PF_SLEEP", 1);
+    a.xshift = (unsigned)env_int("ZGPT2_PF_XSHIFT", 0);
+    a.cls_mask = (unsigned)env_int("ZGPT2_PF_CLASSES", 0x3e);  // lm_head's head start measured a net loss
+    a.line_shift = (unsigned)env_int("ZGPT2_PF_LINE", 7);
+    if (a.line_shift < 6 || a.line_shift > 7) a.line_shift = 7;
+    a.cap_bytes = (unsigned)env_int("ZGPT2_PF_CAP_KB", 0) << 10;
+    a.load_sc1 = (unsigned)env_int("ZGPT2_PF_SC1", 0);
+    if (mode == 1) a.max_T = 0;
+    if (a.lead < 1) a.lead = 1;
+    if (a.nsub < 1) a.nsub = 1;
+    if (a.nsub > 32) a.nsub = 32;
+    g->pf_ran = true;
+    return launch_prefetcher(a, g->pf_stream);
+}
+
+int pf_stop(zg_gpt* g, hipStream_t s) {
+    if (!g->pf_on || s == nullptr) return ZG_OK;
+    ZG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&g->pf_ctl->progress), (int)PF_STOP, 1, s));
     return ZG_OK;
 }
 
@@ -588,8 +739,10 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     g->steps_enqueued = 0;
     g->ln_folded = false;
     {   // every decode graph is captured and instantiated here, not on the first forward that needs it
-        const int st = capture_all(g, ctx().stream);
+        int st = setup_prefetcher(g);
+        if (st == ZG_OK) st = capture_all(g, ctx().stream);
         if (st != ZG_OK) {
+            drop_prefetcher(g);
             drop_graphs(g);
             (void)hipHostFree(g->h_ctrl);
             (void)hipHostFree(g->h_ints);
@@ -605,6 +758,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
 int zg_gpt_destroy(zg_gpt* g) {
     if (!g) return ZG_OK;
     (void)hipStreamSynchronize(ctx().stream);
+    drop_prefetcher(g);
     drop_graphs(g);
     (void)hipFree(g->arena);
     (void)hipHostFree(g->h_ctrl);
@@ -843,7 +997,12 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
         ZG_HIP(hipMemcpyAsync(g->out_tokens, g->prompt, B * C * sizeof(int), hipMemcpyDeviceToDevice, s));
         ZG_TRY(enqueue_prefill(g, first, false, s));
     }
-    for (size_t st = first; st < n_steps; ++st) ZG_TRY(run_step(g, st >= min_prompt, st + 1, s));
+    ZG_TRY(ensure_ln_folded(g, s));
+    ZG_TRY(pf_start(g, n_steps, s));
+    int rs = ZG_OK;
+    for (size_t st = first; st < n_steps && rs == ZG_OK; ++st) rs = run_step(g, st >= min_prompt, st + 1, s);
+    ZG_TRY(pf_stop(g, s));  // also after a failed launch: the prefetcher must not wait for steps that never come
+    ZG_TRY(rs);
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
     g->steps_enqueued = n_steps;
     return ZG_OK;
@@ -938,7 +1097,10 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     hipGraphExec_t exec = nullptr;
     ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int st = ZG_OK;
-    for (int i = 0; i < chain && st == ZG_OK; ++i) st = enqueue_step(g, true, bucket_t_hi(g, T), s, nullptr, which);
+    // ZGPT2_TIME_CYCLE=1 (measurement): walk the layers, so that no launch finds its weights in the L2s
+    const bool cycle = getenv("ZGPT2_TIME_CYCLE") && atoi(getenv("ZGPT2_TIME_CYCLE")) != 0;
+    for (int i = 0; i < chain && st == ZG_OK; ++i)
+        st = enqueue_step(g, true, bucket_t_hi(g, T), s, nullptr, which, cycle ? (size_t)i % g->cfg.n_layer : 0);
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (st != ZG_OK) return st;
     ZG_HIP(ce);
@@ -961,6 +1123,25 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     (void)hipGraphDestroy(graph);
     *avg_us = ms * 1000.0f / (float)(reps * chain);
     if (algorithmic_bytes) *algorithmic_bytes = bytes_tab[which];
+    return ZG_OK;
+}
+
+int zg_debug_prefetch_stats(zg_gpt* g, unsigned* out, size_t n_out) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && out && n_out >= 25, ZG_ERR_ARG, "prefetch_stats: need 25 words");
+    memset(out, 0, n_out * sizeof(unsigned));
+    out[0] = g->pf_on ? (g->pf_stalled ? 2u : 1u) : 0u;
+    if (!g->pf_on) return ZG_OK;
+    ZG_HIP(hipStreamSynchronize(ctx().stream));
+    ZG_HIP(hipStreamSynchronize(g->pf_stream));
+    PfCtl h;
+    ZG_HIP(hipMemcpy(&h, g->pf_ctl, sizeof(PfCtl), hipMemcpyDeviceToHost));
+    for (int x = 0; x < 8; ++x) {
+        out[1 + x] = h.ticket[x];
+        out[9 + x] = h.exit_reason[x];
+        out[17 + x] = h.jobs_done[x];
+    }
+    for (size_t i = 0; i < 256 && 25 + i < n_out; ++i) out[25 + i] = h.xcd_log[i];  // diagnostic (-DZG_STAMPS) builds only
     return ZG_OK;
 }
 

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
                 v4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         }
+        pf_count(a.progress);
         // ---- partial dots, then reduce-scatter: lane (g, j) ends with the score of t = base + 4*j + g
         float s[16];
 #pragma unroll

@@ -153,6 +153,16 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
     const int s = a.ctrl->step;
     const int mode = a.ctrl->mode;
     const int npart = a.n_partials;
+    if (a.progress != nullptr && a.finish_only == 0 && threadIdx.x == 0) {
+        // a step at sequence length s + 1 starts; block 0 of every launch of this queue lands on the XCD this block is on
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID
+        const unsigned long long word = ((unsigned long long)(0x100u | xcc) << 32) | (((unsigned)(s + 1) << 8) | 1u);
+        __hip_atomic_store(static_cast<unsigned long long*>(__builtin_assume_aligned(a.progress, 8)), word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ZG_STAMPS
+        reinterpret_cast<PfCtl*>(a.progress)->xcd_log[0] = 0x100u | xcc;
+#endif
+    }
     const int n_waves = blockDim.x >> 6;
     for (int b = wave; b < a.batch; b += n_waves) {
         // speculative fetch of this sequence's partial maxima (valid memory whether or not needed)

@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 
     // position-dependent scalar (consumed late: merge split count when t_hi == 0, KV scatter position)
     const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    pf_count(a.progress);
     ZG_STAMP(1);
 
     // ---- 1. prologue: build the (transformed) input rows in LDS
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
         bias_n = *(a.bias ? a.bias + n : a.zero);
         resid_n = *(epilogue == EPI_RESIDUAL ? a.resid + n : a.zero);
     }
+    pf_count(a.progress);
 #pragma unroll
     for (int i = 0; i < CPL; ++i)
         if (lr + LPR * i >= nchq) xr[i] = zero_w8();  // clamped surplus chunks multiply zeros
@@ -831,6 +833,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         c3n = c3[n];
     }
     const int T = a.ctrl ? a.ctrl->seq_len : 1;  // KV append position (EPI_QKV)
+    pf_count(a.progress);
     // statistics of this wave's quarter (every LPR-lane group holds the whole quarter) and z = g x
     float sx = 0.0f, sxx = 0.0f;
 #pragma unroll
@@ -1041,6 +1044,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     };
     load_tile(tile_begin);
     const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    pf_count(a.progress);
     ZG_STAMP(1);
     // bias / residual of the FIRST tile are fetched here, next to the weights, instead of one more
     // dependent L2 round trip inside the epilogue
@@ -1548,6 +1552,16 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_ATTN_MERGE && share_merge > 1) wpw = share_merge;
     a.waves_per_wg = wpw;
     return (waves + wpw - 1) / wpw;
+}
+
+// Mirrors the dispatch of launch_gemv below for a planned launch (prefetch.hip follows the same tiles).
+int gemv_rows_per_wg(const GemvArgs& a, int weight_type) {
+    if (gemv_use_mfma(a, weight_type)) return a.kslices > 1 ? 0 : 16 * a.rows_per_wave;
+    const int nchq = a.K / 32;
+    if (gemv_use_ksplit(a)) return 2 * (64 / (nchq <= 32 ? 16 : (nchq <= 224 ? 32 : 64)));  // launch_ksplit
+    if (gemv_use_lnk(a)) return 4 * (64 / (nchq <= 32 ? 16 : (nchq <= 96 ? 32 : 64)));      // launch_lnk
+    if (a.M > 1) return 0;
+    return a.waves_per_wg * a.rows_per_wave;
 }
 
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {

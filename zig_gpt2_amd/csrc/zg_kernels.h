@@ -68,6 +68,7 @@ struct GemvArgs {
     int kslices;
     const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
+    unsigned* progress;       // launch counter followed by the side-stream prefetcher (prefetch.hip); null = not counted
 };
 
 // Whether launch_gemv can run this M x K at all (batched kernels keep the M input rows in LDS).
@@ -75,6 +76,8 @@ bool gemv_supported(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int gemv_kslices(const GemvArgs& a);
+// Rows of W that one workgroup of the planned launch reads (block b: rows b * r .. (b + 1) * r - 1); 0 = another mapping
+int gemv_rows_per_wg(const GemvArgs& a, int weight_type);
 int launch_ln_fold(const void* W, int weight_type, const float* g, const float* b, const float* bias, int N, int K, float* c2,
                    float* c3, hipStream_t s);
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s);
@@ -92,6 +95,7 @@ struct AttnArgs {
     int t_hi;              // launch-time upper bound of seq_len in the same 64-position bucket (>= seq_len)
     int max_splits;
     float* part;  // [B][H][max_splits][kPartStride]
+    unsigned* progress;  // see GemvArgs
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t s);
 // Standalone merge (op tier): out[b][h*hd+d] = sum_s w_s o_s / sum_s w_s l_s
@@ -188,7 +192,68 @@ struct EmbedArgs {
     int n_partials;          // lm_head grid size
     float* x;                // [B][E]
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
+    unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
 };
 int launch_embed_step(const EmbedArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------ decode prefetcher (prefetch.hip)
+enum PfKind { PF_NONE = 0, PF_WEIGHTS = 1, PF_KV = 2 };
+constexpr unsigned PF_STOP = 0xffffffffu;  // value of the progress word that ends the prefetcher
+// What launch `index` of a decode step reads: weights = n_wg contiguous tiles of wg_bytes (block b reads tile b);
+// KV = the rows of earlier positions of one layer's caches, laid out for the (heads, splits, batch) attention grid.
+struct PfJob {
+    const char* base;
+    const char* base2;    // PF_KV: the V cache
+    size_t total_bytes;   // PF_WEIGHTS: end of the matrix (the last tile may be short)
+    unsigned wg_bytes, n_wg;
+    unsigned touch_bytes;  // PF_WEIGHTS: leading part of every tile that is fetched (the whole tile unless the matrix is far larger than the L2s)
+    unsigned kind;
+    unsigned n_heads, ctx, batch, row_bytes;  // PF_KV
+    unsigned cls;          // kernel class of the launch (1 c_attn .. 6 lm_head, as in zg_gpt_profile_step)
+    unsigned pad;
+    // small per-row / per-column vectors every block reads a few lines of (bias, folded-LayerNorm vectors, ln gain):
+    // fetched whole into every XCD — once the weights come from the L2 these are what a block would wait for
+    const char* aux[3];
+    unsigned aux_bytes[3];
+    unsigned pad2;
+};
+struct alignas(8) PfCtl {
+    unsigned progress;    // (T << 8) | launches started in the step at sequence length T;  PF_STOP ends the prefetcher
+    unsigned base_xcd;    // 0x100 | XCC_ID of block 0 of the step's launches (block b then runs on XCD (base + b) % 8);
+                          // written with `progress` as one 64-bit store by the embed kernel
+    unsigned sink_guard, sink;
+    unsigned ticket[8];       // prefetcher workgroups that found themselves on XCD x
+    unsigned exit_reason[8];  // 1 stop, 2 idle limit
+    unsigned jobs_done[8];
+    unsigned xcd_log[256];    // -DZG_STAMPS builds: 0x100 | XCC_ID of block 0 of launch i of the last step
+};
+struct PfArgs {
+    PfCtl* ctl;
+    const PfJob* jobs;  // [njobs]: index 0 = the embed kernel (nothing to fetch), then the step's launches in order
+    int njobs;          // launches of a step with lm_head
+    int lead;           // launches ahead of the running one
+    int nsub;           // prefetcher workgroups per XCD
+    int max_T;          // last sequence length of the generation (nothing is fetched for steps beyond it)
+    unsigned idle_limit;
+    unsigned sleep;     // s_sleep(8) repetitions between polls
+    unsigned xshift;    // measurement: fetch the tiles of XCD (x + xshift) % 8 instead of the own ones
+    unsigned cls_mask;  // bit c set: launches of class c are fetched for
+    unsigned line_shift;  // log2 of the touch stride in bytes (7 = one load per 128-byte line)
+    unsigned load_sc1;    // measurement: agent-scope instead of plain loads
+    unsigned cap_bytes;   // most bytes fetched for one launch (the head of every tile when the matrix is larger); 0 = no cap
+};
+int launch_prefetcher(const PfArgs& a, hipStream_t s);
+
+// Every decode kernel counts itself in at entry (one lane of block 0; fire and forget).
+__device__ __forceinline__ void pf_count(unsigned* progress) {
+    if (progress != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) {
+#ifdef ZG_STAMPS
+        const unsigned old = __hip_atomic_fetch_add(progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<PfCtl*>(progress)->xcd_log[old & 255u] = 0x100u | (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);
+#else
+        __hip_atomic_fetch_add(progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+}
 
 }  // namespace zg

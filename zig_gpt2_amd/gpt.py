@@ -17,13 +17,14 @@ from .synth import GPTConfig
 
 class GPT:
     def __init__(self, config: GPTConfig, batch=1, weights_f32=False, use_graph=True, kv_f16=False, prefill=True,
-                 prefill_planes=3):
+                 prefill_planes=3, prefetch=True):
         self.config, self.batch = config, batch
         L = _lib.load()
         flags = (_lib.GPT_WEIGHTS_F32 if weights_f32 else 0) | (0 if use_graph else _lib.GPT_NO_GRAPH)
         flags |= _lib.GPT_KV_F16 if kv_f16 else 0
         flags |= 0 if prefill else _lib.GPT_NO_PREFILL
         flags |= _lib.GPT_PREFILL_2PLANE if prefill_planes == 2 else 0
+        flags |= 0 if prefetch else _lib.GPT_NO_PREFETCH
         cfg = _lib.GptConfig(config.vocab_size, config.context_size, config.n_layer, config.n_heads, config.n_embed)
         h = C.c_void_p()
         check(L.zg_gpt_create(C.byref(h), C.byref(cfg), batch, flags))
@@ -142,6 +143,13 @@ class GPT:
         out = np.zeros(9, np.float32)
         check(self._L.zg_gpt_profile_step(self.h, seq_len, iters, out.ctypes.data_as(_lib.f32p), out.size))
         return dict(zip(self.PROFILE_CLASSES + ["null_kernel_interval"], (float(v) for v in out)))
+
+    def prefetch_stats(self):
+        """zg_debug_prefetch_stats: {"on", "workgroups", "exit", "jobs"} (lists per XCD) of the last generate call."""
+        out = np.zeros(25 + 256, np.uint32)
+        check(self._L.zg_debug_prefetch_stats(self.h, out.ctypes.data_as(C.c_void_p), out.size))
+        return {"on": bool(out[0]), "stalled": int(out[0]) == 2, "workgroups": out[1:9].tolist(), "exit": out[9:17].tolist(), "jobs": out[17:25].tolist(),
+                "xcd_of_block0": [int(v) & 15 for v in out[25:] if v & 0x100]}
 
     def time_kernel(self, which, iters):
         us, nbytes = C.c_float(), C.c_size_t()
