@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--kv-f16", action="store_true")
     p.add_argument("--weights-f32", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-prefetch", action="store_true", help="no side-stream L2 prefetcher beside the decode chain (A/B)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     p.add_argument("--seed", type=int, default=0)
@@ -206,7 +207,7 @@ def main():
     cfg = synth.CONFIGS[a.model]
     ctx = a.ctx or cfg.context_size
     ppg = a.prompts_per_gpu or (1 if world == 1 else 8)
-    model = gpt.GPT(cfg, batch=ppg, weights_f32=a.weights_f32, use_graph=not a.no_graph, kv_f16=a.kv_f16)
+    model = gpt.GPT(cfg, batch=ppg, weights_f32=a.weights_f32, use_graph=not a.no_graph, kv_f16=a.kv_f16, prefetch=not a.no_prefetch)
 
     # ---- weights: generated and uploaded on rank 0, broadcast to the other GPUs over RCCL/xGMI
     weights = None
@@ -257,6 +258,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ids = model.generate_fetch(ctx)
+    pf = model.prefetch_stats()  # how the side-stream prefetcher of the last generation ended (after the timed region)
 
     # tokens produced per generation: every position after the prompt is one generated token
     gen_tokens = ppg * (ctx - 1)
@@ -378,6 +380,7 @@ def main():
             "vocab": cfg.vocab_size, "context": cfg.context_size, "n_layer": cfg.n_layer, "n_heads": cfg.n_heads,
             "n_embed": cfg.n_embed, "prompts_per_gpu": ppg, "global_prompts": ppg * world,
             "kv_cache": "f16" if a.kv_f16 else "f32", "hip_graph": not a.no_graph,
+            "l2_prefetcher": ("stalled" if pf["stalled"] else "on") if pf["on"] else "off",
             "parallelism": f"replicated weights, prompts sharded x{world}, RCCL broadcast at start-up only",
             "tokens_counted": "generated tokens (context - prompt) per prompt",
         },

@@ -3,7 +3,7 @@
 // weights in registers — and waits on the data itself (every element travels as a {value, tag} pair written with
 // agent-scope stores, the consumer polls until all its tags match) instead of on a kernel boundary?
 //
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/handoff_probe tools/handoff_probe.hip && /tmp/handoff_probe
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/handoff_probe tools/microbench/handoff_probe.hip && /tmp/handoff_probe
 //
 // A "step" is a chain of L stages y <- W_k y (N = K, bf16 weights, fp32 pairs) replayed as a hipGraph:
 //   mode 0: one stream, plain loads, no tags            (today's design: launch boundary per stage)

@@ -1,7 +1,7 @@
 // Development probe: which XCD (HW_REG_XCC_ID) do the blocks of consecutive launches of a replayed hipGraph land on?
 // A chain of kernels with the decode step's grid sizes; every block records its XCC_ID.  Prints, per replay and per
 // kernel, the XCD of block 0 and whether block b sits on (xcd(block 0) + b) % 8 throughout.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/xcd_probe tools/xcd_probe.hip && /tmp/xcd_probe
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/xcd_probe tools/microbench/xcd_probe.hip && /tmp/xcd_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

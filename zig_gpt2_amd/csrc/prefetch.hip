@@ -5,7 +5,7 @@
 // the memory side (Infinity Cache or HBM), never in its XCD's L2: tools/cold_chain.py prices that at +0.35..0.85 us
 // per launch (+13 % of a token) against the same kernel re-reading the same layer.  A launch cannot fetch for its
 // successor (s_endpgm waits for a wave's outstanding loads, so the fetch would only move into the earlier
-// kernel), and branches of a captured graph are not co-resident (tools/handoff_probe.hip).  What does overlap
+// kernel), and branches of a captured graph are not co-resident (tools/microbench/handoff_probe.hip).  What does overlap
 // with the chain is a SEPARATE, low-priority stream: one persistent kernel of a few workgroups per XCD that
 // follows the chain's progress counter and touches, one or two kernels ahead, the cache lines the upcoming kernel's
 // workgroups ON THE SAME XCD will read.  Blocks are dealt round robin over the XCDs starting at a queue-dependent
