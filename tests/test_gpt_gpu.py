@@ -286,3 +286,23 @@ def test_prompt_as_long_as_the_context(zg):
     ids_ref = oracle.GPT(cfg, w).generate_greedy(prompts[1], cfg.context_size)
     assert np.array_equal(ids[1], ids_ref)
     m.close()
+
+
+@pytest.mark.parametrize("steps", [1, 4, 16])
+def test_steps_per_graph_do_not_change_tokens(zg, monkeypatch, steps):
+    """The generate loop replays graphs of several consecutive steps (default 8, ZGPT2_GRAPH_STEPS): same ids as one
+    step per graph, for prompts and lengths that are not multiples of the group."""
+    cfg = synth.CONFIGS["nano-char"]
+    w = synth.make_weights(cfg, seed=31, bf16=True)
+    prompts = [synth.rand_tokens(311, 5, cfg.vocab_size)]
+    m = zgpt.GPT(cfg, prefill=False)  # default grouping
+    m.load_weights(w)
+    ref = {n: m.generate(prompts, n)[0] for n in (7, 61, cfg.context_size)}
+    m.close()
+    monkeypatch.setenv("ZGPT2_GRAPH_STEPS", str(steps))
+    m = zgpt.GPT(cfg, prefill=False)
+    m.load_weights(w)
+    for n, want in ref.items():
+        assert np.array_equal(m.generate(prompts, n)[0], want), (steps, n)
+    m.close()
+

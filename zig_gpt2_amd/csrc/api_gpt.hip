@@ -64,6 +64,8 @@ struct zg_gpt {
     // The bucket's upper bound t_hi is baked into the attention / merge kernels so that their loads
     // do not wait for the exact seq_len (which lives in device memory).
     std::vector<hipGraphExec_t> graphs;
+    std::vector<hipGraphExec_t> graphs_k;  // per bucket: graph_steps consecutive steps with lm_head in one graph (generate loop)
+    size_t graph_steps;
     hipStream_t graph_stream;
     size_t steps_enqueued;
     bool ln_folded;  // c2 / c3 of every layer match the weights currently in the arena
@@ -591,11 +593,12 @@ size_t prefill_min() {
 }
 
 void drop_graphs(zg_gpt* g) {
-    for (auto& e : g->graphs)
-        if (e) {
-            (void)hipGraphExecDestroy(e);
-            e = nullptr;
-        }
+    for (auto* v : {&g->graphs, &g->graphs_k})
+        for (auto& e : *v)
+            if (e) {
+                (void)hipGraphExecDestroy(e);
+                e = nullptr;
+            }
 }
 
 // Run one decode step at sequence length seq_len: replay the graph of its bucket (capturing it on
@@ -619,6 +622,26 @@ int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
     return ZG_OK;
 }
 
+// graph_steps consecutive decode steps (all with lm_head, all in 64-position bucket b) as ONE graph: the position lives
+// in device memory, so the same kernels simply repeat; saves the gap between graph launches in the generate loop.
+int capture_multi(zg_gpt* g, size_t b, hipStream_t s) {
+    if (g->graphs_k.size() <= b) g->graphs_k.resize(b + 1, nullptr);
+    if (g->graphs_k[b]) return ZG_OK;
+    hipGraph_t graph = nullptr;
+    ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int st = ZG_OK;
+    for (size_t i = 0; i < g->graph_steps && st == ZG_OK; ++i) st = enqueue_step(g, true, bucket_t_hi(g, (b + 1) * 64), s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (st != ZG_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return st;
+    }
+    ZG_HIP(e);
+    ZG_HIP(hipGraphInstantiate(&g->graphs_k[b], graph, nullptr, nullptr, 0));
+    ZG_HIP(hipGraphDestroy(graph));
+    return ZG_OK;
+}
+
 // All decode graphs of a handle (two per 64-position bucket: with / without lm_head) for stream s.  Called from
 // zg_gpt_create — the State.init moment (main.zig:46-64) — so that no forward allocates; a later zg_set_stream
 // re-captures them on the first call that sees the new stream.
@@ -630,6 +653,8 @@ int capture_all(zg_gpt* g, hipStream_t s) {
     }
     const size_t n = ((g->cfg.context_size + 63) / 64) * 2;
     for (size_t idx = 0; idx < n; ++idx) ZG_TRY(capture_bucket(g, idx, s));
+    if (g->graph_steps > 1)
+        for (size_t b = 0; b < n / 2; ++b) ZG_TRY(capture_multi(g, b, s));
     return ZG_OK;
 }
 
@@ -738,6 +763,11 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     }
     g->steps_enqueued = 0;
     g->ln_folded = false;
+    {   // decode steps per graph in the generate loop: a graph launch costs ~7 us of idle queue (124M: 224.8 us per token
+        // with 1 step per graph, 220.4 with 2 / 4, 218.3 with 8, 219.5 with 16)
+        const int k = env_int("ZGPT2_GRAPH_STEPS", 8);
+        g->graph_steps = (k == 2 || k == 4 || k == 8 || k == 16) ? (size_t)k : 1;
+    }
     {   // every decode graph is captured and instantiated here, not on the first forward that needs it
         int st = setup_prefetcher(g);
         if (st == ZG_OK) st = capture_all(g, ctx().stream);
@@ -1000,7 +1030,22 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(pf_start(g, n_steps, s));
     int rs = ZG_OK;
-    for (size_t st = first; st < n_steps && rs == ZG_OK; ++st) rs = run_step(g, st >= min_prompt, st + 1, s);
+    const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;
+    for (size_t st = first; st < n_steps && rs == ZG_OK;) {
+        if (K > 1 && st >= min_prompt && st % K == 0 && st + K <= n_steps && st + K <= C) {
+            if (g->graph_stream != s) rs = capture_all(g, s);
+            const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
+            if (rs == ZG_OK) rs = capture_multi(g, b, s);
+            if (rs == ZG_OK) {
+                const hipError_t le = hipGraphLaunch(g->graphs_k[b], s);
+                if (le != hipSuccess) rs = hip_fail(le, "hipGraphLaunch", __FILE__, __LINE__);
+            }
+            st += K;
+        } else {
+            rs = run_step(g, st >= min_prompt, st + 1, s);
+            ++st;
+        }
+    }
     ZG_TRY(pf_stop(g, s));  // also after a failed launch: the prefetcher must not wait for steps that never come
     ZG_TRY(rs);
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
