@@ -9,14 +9,14 @@ import json
 import sys
 
 CLASSES = {  # bench.py kernel class -> kernel symbol (substring of the rocprof name) at 124M, one prompt, bf16 weights
-    "ln_1 + c_attn + KV append": "gemv_lnk_kernel<unsigned short, 16, 2>",
+    "ln_1 + c_attn + KV append": "gemv_lnk_kernel<unsigned short, 16, 2, 4>",
     "attention (split-KV decode)": "attn_decode_kernel<float>",
-    "head merge + attn c_proj + residual": "gemv_kernel<unsigned short, 1, 16, 6, false>",
-    "ln_2 + c_fc + GELU": "gemv_lnk_kernel<unsigned short, 16, 2>",
-    "mlp c_proj + residual": "gemv_ksplit_kernel<unsigned short, 32, 3>",
+    "head merge + attn c_proj + residual": "gemv_ksplit_kernel<unsigned short, 16, 2, 2>",
+    "ln_2 + c_fc + GELU": "gemv_lnk_kernel<unsigned short, 16, 2, 4>",
+    "mlp c_proj + residual": "gemv_ksplit_kernel<unsigned short, 32, 3, 2>",
     "ln_f + lm_head + argmax": "gemv_kernel<unsigned short, 1, 16, 6, true>",
 }
-NOTE = {"gemv_lnk_kernel<unsigned short, 16, 2>": "kernel shared by c_attn (3.54 MB) and c_fc (4.72 MB): average of both"}
+NOTE = {"gemv_lnk_kernel<unsigned short, 16, 2, 4>": "kernel shared by c_attn (3.54 MB) and c_fc (4.72 MB): average of both"}
 
 
 def row(path, sym, col):

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""The leanest target for rocprofv3 --pmc passes over the decode step: one full-context greedy generation of GPT-2
+124M, one prompt, eager launches, no prefetcher (every kernel's own traffic), the stream drained every 16 steps
+(rocprofv3 7.2's counter collection crashes behind long queues and over graph replays).  Nothing else runs."""
+import os, sys
+os.environ.setdefault("ZGPT2_SYNC_EVERY", "16")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from zig_gpt2_amd import _lib, gpt, synth
+lib = _lib.load(); _lib.check(lib.zg_init(0))
+stream = torch.cuda.Stream(); _lib.check(lib.zg_set_stream(stream.cuda_stream))
+cfg = synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "124M"]
+m = gpt.GPT(cfg, batch=1, use_graph=False, prefetch=False, prefill=False)
+ids = m.generate([synth.rand_tokens(1000, 1, cfg.vocab_size)], cfg.context_size)
+print("generated", ids.shape, flush=True)
+m.close()

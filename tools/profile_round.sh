@@ -6,20 +6,30 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 # 1. kernel trace + stats of the default benchmark command (full 1024-position context)
-rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
 python tools/rocpd_stats.py $(find $out/trace -name "*.db" | head -1) $out/${tag}_kernel_stats.md > /dev/null
+rm -rf $out/trace
+# 1b. the same without the side-stream L2 prefetcher: the per-kernel durations it changes
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prefetch > $out/bench_under_rocprof_noprefetch.json 2> $out/bench_under_rocprof_noprefetch.err
+python tools/rocpd_stats.py $(find $out/trace -name "*.db" | head -1) $out/${tag}_kernel_stats_noprefetch.md > /dev/null
 rm -rf $out/trace
 # 2. HBM traffic counters of the same workload at the full 1024-position context, separate passes.  Eager launches
 #    (--no-graph: the same kernels without hipGraph replay) — rocprofv3 7.2 segfaults collecting counters over
-#    graph replays of more than a few hundred steps.
+#    graph replays of more than a few hundred steps, and intermittently behind long queues: tools/pmc_decode.py is the
+#    leanest target (one generation, no prefetcher: every kernel's own traffic), retried when the tool crashes.
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $out/pmc_$c.json 2> $out/pmc_$c.err
-  python tools/rocpd_pmc.py $(find $out/pmc_$c -name "*.db" | head -1) $out/${tag}_pmc_$c.md > /dev/null 2> $out/pmc_${c}_parse.err
-  rm -rf $out/pmc_$c
+  for attempt in 1 2 3; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o pmc -- python3 tools/pmc_decode.py > $out/pmc_$c.log 2> $out/pmc_$c.err
+    python tools/rocpd_pmc.py $(find $out/pmc_$c -name "*.db" | head -1) $out/${tag}_pmc_$c.md.new > /dev/null 2> $out/pmc_${c}_parse.err
+    rm -rf $out/pmc_$c
+    # a crashed pass leaves no empty table behind; try again
+    if [ -s $out/${tag}_pmc_$c.md.new ]; then mv $out/${tag}_pmc_$c.md.new $out/${tag}_pmc_$c.md; break; fi
+  done
 done
 python tools/make_traffic_json.py $out $tag > /dev/null 2> $out/traffic.err
 # 3. un-profiled lines: the headline config and the other BASELINE configs
 python bench.py --steps 5 --warmup 1 > $out/${tag}_bench.json 2> $out/bench.err
+python bench.py --steps 5 --warmup 1 --no-prefetch --no-cpu-baseline > $out/${tag}_bench_noprefetch.json 2> $out/bench_noprefetch.err
 python bench.py --steps 3 --warmup 1 --prompts-per-gpu 8 --no-cpu-baseline > $out/${tag}_bench_8prompts.json 2> $out/bench_8prompts.err
 python bench.py --steps 2 --warmup 1 --model xl --no-cpu-baseline > $out/${tag}_bench_xl.json 2> $out/bench_xl.err
 python bench.py --steps 5 --warmup 1 --model nano-char --no-cpu-baseline > $out/${tag}_bench_nano_char.json 2> $out/bench_nano_char.err

@@ -1031,7 +1031,15 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_TRY(pf_start(g, n_steps, s));
     int rs = ZG_OK;
     const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;
+    // ZGPT2_SYNC_EVERY=n (profiling only): drain the stream every n steps — rocprofv3's counter collection has crashed
+    // on this stack when tens of thousands of dispatches were queued ahead of it
+    static const int sync_every = env_int("ZGPT2_SYNC_EVERY", 0);
+    size_t since_sync = 0;
     for (size_t st = first; st < n_steps && rs == ZG_OK;) {
+        if (sync_every > 0 && ++since_sync >= (size_t)sync_every) {
+            since_sync = 0;
+            (void)hipStreamSynchronize(s);
+        }
         if (K > 1 && st >= min_prompt && st % K == 0 && st + K <= n_steps && st + K <= C) {
             if (g->graph_stream != s) rs = capture_all(g, s);
             const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)

@@ -31,6 +31,7 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_a
 // One 4-byte load per 128-byte line: the line lands in this XCD's L2, the value is discarded.  A plain load: the
 // compiler waits for it only where the value is consumed (a `volatile` one is waited for on the spot).
 __device__ __forceinline__ unsigned touch(const char* p) { return *reinterpret_cast<const unsigned*>(p); }
+__device__ __forceinline__ unsigned touch_nt(const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)); }
 __device__ __forceinline__ unsigned touch_sc1(const char* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -46,11 +47,11 @@ struct Pending {
 #define ZG_PF_SLOT(u, cond, addr)                \
     {                                             \
         sink ^= pend.v[u];                        \
-        pend.v[u] = (cond) ? (sc1 ? touch_sc1(addr) : touch(addr)) : 0u; \
+        pend.v[u] = (cond) ? (sc1 == 1 ? touch_sc1(addr) : (sc1 == 2 ? touch_nt(addr) : touch(addr))) : 0u; \
     }
 
 __device__ __forceinline__ unsigned prefetch_job(const PfJob& j, unsigned mine, unsigned gt, unsigned stride, unsigned T, unsigned ls,
-                                                 unsigned cap_bytes, Pending& pend, bool sc1) {
+                                                 unsigned cap_bytes, Pending& pend, unsigned sc1) {
     unsigned sink = 0;
     if (j.kind == PF_WEIGHTS) {
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const PfArgs a) {
             const unsigned idx = (unsigned)(cursor % njobs);
             const unsigned Tj = (unsigned)(cursor / njobs);
             if (Tj <= (unsigned)a.max_T && ((a.cls_mask >> s_jobs[idx].cls) & 1u))
-                sink ^= prefetch_job(s_jobs[idx], mine, gt, stride, Tj, a.line_shift, a.cap_bytes, pend, a.load_sc1 != 0);
+                sink ^= prefetch_job(s_jobs[idx], mine, gt, stride, Tj, a.line_shift, a.cap_bytes, pend, a.load_sc1);
             ++cursor;
             ++jobs_done;
         }
