@@ -1008,7 +1008,12 @@ __device__ __forceinline__ void store_split4(char* planes, int S, int m, int k, 
 // single workgroup per tile spent half of its time staging 8 x 3072 activations).  The slices' partial tiles meet in a
 // workspace and are combined in FIXED slice order by the last workgroup of the tile to arrive.  A template parameter,
 // so that the KSL == 1 kernels are untouched (two more leading scalar arguments cost them 6 % in situ).
-template <int KS, int NW, bool ARGMAX, int KSL = 1>
+// LINE: the weights are fetched as full 128-byte lines — lane = (row >> 3, 16-B piece & 7), two instructions cover 16
+// rows x 64 k — and turned into B fragments through a wave-private 2-KiB LDS slot (see lm_head_wpt_kernel): the B
+// fragment layout itself puts 16 different rows into the 16 lanes of a group, i.e. half a line per row per
+// instruction, which costs 0.5..0.8 us per launch at 124M and 1.2..2.3 us at GPT-2 XL (8 sequences).  A wave then owns
+// PAIRS of 32-k steps (wave + NW i); needs K % 64 == 0 and room for the slots.
+template <int KS, int NW, bool ARGMAX, int KSL = 1, bool LINE = false>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin,
                                                             int N, int K, int M, int tiles_per_wg, int prologue,
                                                             int epilogue, const float* __restrict__ ln_g,
@@ -1033,13 +1038,28 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     const int brow = lane & 15, bq = lane >> 4;  // B fragment: weight row within the tile, k quarter
 
     // ---- 0. first tile's weight fragments: independent of everything else
-    u32x4 wq[KS];
+    constexpr int KP = (KS + 1) / 2;  // LINE: pairs of steps per wave
+    const int npairs = nsteps >> 1;
+    const int lrow = lane >> 3, lpc = lane & 7;  // LINE load shape: row within the half tile, 16-B piece of the line
+    u32x4 wq[LINE ? 2 * KP : KS];
     auto load_tile = [&](int tile) {
-        const bf16_t* wp = W + (size_t)min(min(tile, ntiles - 1) * 16 + brow, N - 1) * ldw + bq * 8;
+        if constexpr (LINE) {  // wq[2 i] = rows 0..7, wq[2 i + 1] = rows 8..15 of the k range of pair wave + NW i
+            const int r0 = min(tile, ntiles - 1) * 16 + lrow;
+            const bf16_t* p0 = W + (size_t)min(r0, N - 1) * ldw + lpc * 8;
+            const bf16_t* p1 = W + (size_t)min(r0 + 8, N - 1) * ldw + lpc * 8;
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
-            const int st = min(wave + NW * i, nsteps - 1);  // surplus steps re-read the last one (weight 0 below)
-            wq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + st * 32));
+            for (int i = 0; i < KP; ++i) {
+                const int q = min(wave + NW * i, npairs - 1);  // surplus pairs re-read the last one (weight 0 below)
+                wq[2 * i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + q * 64));
+                wq[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p1 + q * 64));
+            }
+        } else {
+            const bf16_t* wp = W + (size_t)min(min(tile, ntiles - 1) * 16 + brow, N - 1) * ldw + bq * 8;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const int st = min(wave + NW * i, nsteps - 1);  // surplus steps re-read the last one (weight 0 below)
+                wq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + st * 32));
+            }
         }
     };
     load_tile(tile_begin);
@@ -1220,22 +1240,54 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     // workgroup owns a single tile, the partial tiles reuse the plane area once every wave has read its fragments.
     const bool alias_partial = a.waves_per_wg < 0;
     float* partial = alias_partial ? reinterpret_cast<float*>(planes) : red + 64;
+    // LINE: transposing slot of this wave behind the partial tiles — row rho (0..15) x 8 pieces of 16 B, piece p at
+    // p ^ ((rho >> 1) & 7): the line-shaped writes and the fragment-shaped reads are both conflict free
+    char* lslot = reinterpret_cast<char*>(red + 64 + 2 * NW * 64 * 4) + wave * 2048;
+    const int wr0 = lrow * 128 + ((lpc ^ ((lrow >> 1) & 7)) << 4);
+    const int wr1 = (lrow + 8) * 128 + ((lpc ^ (((lrow + 8) >> 1) & 7)) << 4);
+    const int rd0 = brow * 128 + ((bq ^ ((brow >> 1) & 7)) << 4);        // step 2 q:     k = 64 q + 8 bq
+    const int rd1 = brow * 128 + (((4 + bq) ^ ((brow >> 1) & 7)) << 4);  // step 2 q + 1: k = 64 q + 32 + 8 bq
     int buf = 0;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         mf_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (LINE) {
+            mf_f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
-            const int st = wave + NW * i;
-            const int stc = min(st, nsteps - 1);
-            u32x4 wv = wq[i];
-            if (st >= nsteps) wv = u32x4{0u, 0u, 0u, 0u};
-            const mf_bf16x8 b = __builtin_bit_cast(mf_bf16x8, wv);
-            const mf_bf16x8 a_lo = *reinterpret_cast<const mf_bf16x8*>(arow + 2 * plane + stc * 64);
-            const mf_bf16x8 a_mid = *reinterpret_cast<const mf_bf16x8*>(arow + plane + stc * 64);
-            const mf_bf16x8 a_hi = *reinterpret_cast<const mf_bf16x8*>(arow + stc * 64);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, b, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
+            for (int i = 0; i < KP; ++i) {
+                const int q = wave + NW * i;
+                const int qc = min(q, npairs - 1);
+                *reinterpret_cast<u32x4*>(lslot + wr0) = wq[2 * i];
+                *reinterpret_cast<u32x4*>(lslot + wr1) = wq[2 * i + 1];
+                __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
+                u32x4 v0 = *reinterpret_cast<const u32x4*>(lslot + rd0);
+                u32x4 v1 = *reinterpret_cast<const u32x4*>(lslot + rd1);
+                __builtin_amdgcn_wave_barrier();
+                if (q >= npairs) v0 = v1 = u32x4{0u, 0u, 0u, 0u};
+                const mf_bf16x8 b0 = __builtin_bit_cast(mf_bf16x8, v0), b1 = __builtin_bit_cast(mf_bf16x8, v1);
+#pragma unroll
+                for (int p = 2; p >= 0; --p) {  // smallest plane first
+                    const mf_bf16x8 a0 = *reinterpret_cast<const mf_bf16x8*>(arow + p * plane + (2 * qc) * 64);
+                    const mf_bf16x8 a1 = *reinterpret_cast<const mf_bf16x8*>(arow + p * plane + (2 * qc + 1) * 64);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
+                }
+            }
+            acc += acc1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const int st = wave + NW * i;
+                const int stc = min(st, nsteps - 1);
+                u32x4 wv = wq[i];
+                if (st >= nsteps) wv = u32x4{0u, 0u, 0u, 0u};
+                const mf_bf16x8 b = __builtin_bit_cast(mf_bf16x8, wv);
+                const mf_bf16x8 a_lo = *reinterpret_cast<const mf_bf16x8*>(arow + 2 * plane + stc * 64);
+                const mf_bf16x8 a_mid = *reinterpret_cast<const mf_bf16x8*>(arow + plane + stc * 64);
+                const mf_bf16x8 a_hi = *reinterpret_cast<const mf_bf16x8*>(arow + stc * 64);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
+            }
         }
         if (tile == tile_begin) ZG_STAMP(4);
         if (tile + 1 < tile_end) load_tile(tile + 1);  // next tile's weights fly under the epilogue
@@ -1336,11 +1388,204 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     ZG_STAMP_FLUSH();
 }
 
+// ================================================================================================
+// Vocabulary projection (ln_f + lm_head + greedy partial argmax) for 2..8 sequences: ONE WAVE PER 16-ROW TILE over the
+// whole K, weights fetched as FULL 128-BYTE LINES.
+//
+// What bounded the K-split kernel above on this matrix (24.6 us per launch = 3.1 TB/s for the 77 MB of 124M's wte) was
+// neither its per-tile exchange / barrier nor the MFMAs (the same kernel without them: 24.5 us) but the shape of its
+// weight loads: the B fragment of v_mfma_f32_16x16x32_bf16 puts 16 different rows in the 16 lanes of a group, so one
+// load instruction touches 16 rows x 64 B — half a line of each, the other half by the next instruction.  The same
+// bytes fetched as 8 rows x 128 B per instruction stream at 17.3 us (4.5 TB/s).  So a wave loads line-shaped pieces
+// (lane = row >> 3, 16-B piece & 7; two instructions cover 16 rows x 64 k), turns them into B fragments through a
+// wave-private 2-KiB LDS slot (one ds_write_b128 and one ds_read_b128 per load, XOR-swizzled, conflict free; LDS
+// operations of one wave complete in order, so no barrier), multiplies them with the three activation planes the
+// workgroup built once, runs the epilogue on its own accumulators and moves on: no cross-wave exchange and no
+// workgroup barrier inside the tile loop.  Same products as the K-split kernel, summed in two fp32 chains (even / odd
+// 32-k steps).
+template <int NS>  // 32-k steps per tile: K = 32 NS, NS even
+__global__ __launch_bounds__(256) void lm_head_wpt_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin, int N,
+                                                          int K, int M, int tiles_per_wg, const float* __restrict__ ln_g,
+                                                          const float* __restrict__ ln_b, const GemvArgs a) {
+    static_assert(NS % 2 == 0, "pairs of 32-k steps");
+    extern __shared__ __attribute__((aligned(16))) char smem_mf[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = 2 * K + 16;
+    char* planes = smem_mf;                                                       // [3][8][S]
+    Best* s_best = reinterpret_cast<Best*>(smem_mf + (size_t)3 * kMfmaRows * S);  // [4 waves][8 rows]
+    char* slot = smem_mf + (size_t)3 * kMfmaRows * S + 4 * kMfmaRows * sizeof(Best) + wave * 4096;  // 2 x 2 KiB per wave
+    const int ntiles = (N + 15) >> 4;
+    const int tile_begin = blockIdx.x * tiles_per_wg;
+    const int tile_end = min(tile_begin + tiles_per_wg, ntiles);
+    const int brow = lane & 15, bq = lane >> 4;  // B fragment: weight row within the tile, k quarter
+    const int lrow = lane >> 3, lpc = lane & 7;  // load shape: row within the half tile, 16-B piece of the 128-B line
+
+    // wq[2 j] = rows 0..7, wq[2 j + 1] = rows 8..15 of the k range [64 j, 64 j + 64)
+    u32x4 wq[NS];
+    auto load_tile = [&](int tile) {
+        const int r0 = min(tile, ntiles - 1) * 16 + lrow;
+        const bf16_t* p0 = W + (size_t)min(r0, N - 1) * K + lpc * 8;
+        const bf16_t* p1 = W + (size_t)min(r0 + 8, N - 1) * K + lpc * 8;
+#pragma unroll
+        for (int j = 0; j < NS / 2; ++j) {
+            wq[2 * j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + j * 64));
+            wq[2 * j + 1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p1 + j * 64));
+        }
+    };
+    int tile = tile_begin + wave;
+    load_tile(tile);  // independent of everything else
+    const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    pf_count(a.progress);
+
+    // ---- prologue: wave w normalises rows w and w + 4 (LayerNorm.forward, ops.zig:82-104: single pass sum / sum of
+    // squares) and writes them as three bf16 planes; no cross-wave statistics
+    constexpr int JT = (NS * 8 + 63) / 64;  // float4 per lane per row
+    const int nq = K >> 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = wave + 4 * j;
+        f32x4 v[JT], g4[JT], b4[JT];
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+            const int ic = min(lane + 64 * t, nq - 1);
+            g4[t] = reinterpret_cast<const f32x4*>(ln_g)[ic];
+            b4[t] = reinterpret_cast<const f32x4*>(ln_b)[ic];
+            v[t] = reinterpret_cast<const f32x4*>(xin + (size_t)min(m, M - 1) * a.x_stride)[ic];
+        }
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+            if (lane + 64 * t >= nq) v[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            t1 += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+            t2 = fmaf(v[t].x, v[t].x, fmaf(v[t].y, v[t].y, fmaf(v[t].z, v[t].z, fmaf(v[t].w, v[t].w, t2))));
+        }
+        t1 = wave_allsum(t1);
+        t2 = wave_allsum(t2);
+        const float inv_k = 1.0f / (float)K;
+        const float mean = t1 * inv_k;
+        const float rstd = __builtin_amdgcn_rsqf(t2 * inv_k - mean * mean + a.eps);
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+            if (lane + 64 * t < nq) {
+                f32x4 o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (m < M) {
+                    o.x = fmaf((v[t].x - mean) * rstd, g4[t].x, b4[t].x);
+                    o.y = fmaf((v[t].y - mean) * rstd, g4[t].y, b4[t].y);
+                    o.z = fmaf((v[t].z - mean) * rstd, g4[t].z, b4[t].z);
+                    o.w = fmaf((v[t].w - mean) * rstd, g4[t].w, b4[t].w);
+                }
+                store_split4(planes, S, m, (lane + 64 * t) * 4, o);
+            }
+        }
+    }
+    __syncthreads();
+
+    Best best[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        best[r].val = -3.0e38f;
+        best[r].idx = 0x7fffffff;
+    }
+    const int pos = T - 1;
+    const size_t plane = (size_t)kMfmaRows * S;
+    const char* arow = planes + (size_t)(lane & 7) * S + bq * 16;  // A fragment: batch row (lane & 15) & 7
+    // transposing slot: row rho (0..15) x 8 pieces of 16 B, piece p stored at p ^ ((rho >> 1) & 7)
+    const int wr0 = lrow * 128 + ((lpc ^ ((lrow >> 1) & 7)) << 4);              // rows 0..7
+    const int wr1 = (lrow + 8) * 128 + ((lpc ^ (((lrow + 8) >> 1) & 7)) << 4);  // rows 8..15
+    const int rd0 = brow * 128 + ((bq ^ ((brow >> 1) & 7)) << 4);        // step 2 j:     k = 64 j + 8 bq
+    const int rd1 = brow * 128 + (((4 + bq) ^ ((brow >> 1) & 7)) << 4);  // step 2 j + 1: k = 64 j + 32 + 8 bq
+    for (; tile < tile_end; tile += 4) {
+        mf_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        // the A fragments are the same for every tile: an opaque offset keeps the compiler from hoisting all 3 NS of
+        // them out of the tile loop (288 registers at K = 768)
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        const char* ar = arow + opaque;
+#pragma unroll
+        for (int j = 0; j < NS / 2; ++j) {
+            char* sl = slot + (j & 1) * 2048;
+            *reinterpret_cast<u32x4*>(sl + wr0) = wq[2 * j];
+            *reinterpret_cast<u32x4*>(sl + wr1) = wq[2 * j + 1];
+            __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
+            const mf_bf16x8 b0 = *reinterpret_cast<const mf_bf16x8*>(sl + rd0);
+            const mf_bf16x8 b1 = *reinterpret_cast<const mf_bf16x8*>(sl + rd1);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 2; p >= 0; --p) {  // smallest plane first
+                const mf_bf16x8 a0 = *reinterpret_cast<const mf_bf16x8*>(ar + p * plane + (2 * j) * 64);
+                const mf_bf16x8 a1 = *reinterpret_cast<const mf_bf16x8*>(ar + p * plane + (2 * j + 1) * 64);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
+            }
+        }
+        const mf_f32x4 acc = acc0 + acc1;
+        const int n = tile * 16 + brow;
+        if (tile + 4 < tile_end) load_tile(tile + 4);  // the next tile's weights fly under this tile's epilogue
+        if (lane < 32 && n < N) {  // lanes 0..31 hold batch rows 0..7 (rows 8..15 of the tile alias them)
+            const float bias_n = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bq * 4 + r;
+                if (m < M) epilogue_row(a, m, n, acc[r], bias_n, 0.0f, pos, best[r]);
+            }
+        }
+    }
+
+    // ---- greedy partials: rows m = 4 bq + r live in the 16 lanes of DPP row bq; then across the four waves
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Best b = best[r];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            Best o;
+            o.val = __shfl_xor(b.val, off, 64);
+            o.idx = __shfl_xor(b.idx, off, 64);
+            b = better(b, o);
+        }
+        if (brow == 0 && lane < 32) s_best[wave * kMfmaRows + bq * 4 + r] = b;
+    }
+    __syncthreads();
+    if (tid < M) {
+        Best b = s_best[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = better(b, s_best[w * kMfmaRows + tid]);
+        a.part_val[(size_t)tid * gridDim.x + blockIdx.x] = b.val;
+        a.part_idx[(size_t)tid * gridDim.x + blockIdx.x] = b.idx;
+    }
+}
+
+// Which lm_head launches take the wave-per-tile kernel: the K values whose tile fits a wave's registers.
+inline int lm_wpt_steps(const GemvArgs& a) {
+    static const int off = getenv("ZGPT2_NO_LM_WPT") ? atoi(getenv("ZGPT2_NO_LM_WPT")) : 0;
+    if (off || a.epilogue != EPI_ARGMAX || a.prologue != PRO_LAYERNORM || a.M < 2 || a.M > kMfmaRows || a.K % 32 != 0) return 0;
+    const int ns = a.K / 32;
+    return (ns == 12 || ns == 24 || ns == 32) ? ns : 0;
+}
+inline int lm_wpt_tiles_per_wg() {  // a multiple of the four waves
+    static const int v = getenv("ZGPT2_LM_WPT_TILES") ? atoi(getenv("ZGPT2_LM_WPT_TILES")) : 8;
+    return v >= 4 ? (v / 4) * 4 : 4;
+}
+
+template <int NS>
+int launch_lm_wpt(const GemvArgs& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)3 * kMfmaRows * (2 * a.K + 16) + 4 * kMfmaRows * sizeof(Best) + 4 * 4096;
+    hipLaunchKernelGGL((lm_head_wpt_kernel<NS>), dim3(grid), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K,
+                       a.M, a.rows_per_wave, a.ln_g, a.ln_b, a);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 inline int gemv_mfma_waves(const GemvArgs& a) { return a.epilogue == EPI_ARGMAX ? 4 : 16; }
 
-inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false) {
+inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false, bool line = false) {
     const size_t planes = (size_t)3 * kMfmaRows * (2 * K + 16);
-    return planes + 64 * sizeof(float) + (alias_partial ? 0 : (size_t)2 * nw * 64 * 4 * sizeof(float));
+    return planes + 64 * sizeof(float) + (alias_partial ? 0 : (size_t)2 * nw * 64 * 4 * sizeof(float)) + (line ? (size_t)nw * 2048 : 0);
+}
+// full-line weight loads (LINE instantiations): whole pairs of 32-k steps and room for one 2-KiB slot per wave
+inline bool gemv_mfma_line(int K, int nw, bool alias_partial) {
+    static const int off = getenv("ZGPT2_NO_LINE_LOADS") ? atoi(getenv("ZGPT2_NO_LINE_LOADS")) : 0;
+    return !off && !alias_partial && K % 64 == 0 && gemv_mfma_lds(K, nw, false, true) <= 160 * 1024;
 }
 
 // single-tile workgroups may let the partial tiles alias the planes (see the kernel)
@@ -1348,23 +1593,29 @@ inline bool gemv_mfma_alias(const GemvArgs& a) {
     return a.kslices <= 1 && a.epilogue != EPI_ARGMAX && a.rows_per_wave == 1 && gemv_mfma_lds(a.K, 16) > 160 * 1024;
 }
 
-template <int KS, int NW, bool ARGMAX, int KSL = 1>
-int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
-    const bool alias = KSL == 1 && gemv_mfma_alias(a);
-    const size_t lds = gemv_mfma_lds(a.K / KSL, NW, alias);
+template <int KS, int NW, bool ARGMAX, int KSL, bool LINE>
+int launch_mfma_inst2(const GemvArgs& a, int grid, bool alias, hipStream_t s) {
+    const size_t lds = gemv_mfma_lds(a.K / KSL, NW, alias, LINE);
     GemvArgs b = a;
     b.waves_per_wg = alias ? -1 : NW;  // < 0: partial tiles alias the planes
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX, KSL>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX, KSL>), dim3(grid, KSL), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE>), dim3(grid, KSL), dim3(NW * 64), lds, s,
                        reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K / KSL, a.M, a.rows_per_wave, a.prologue,
                        a.epilogue, a.ln_g, a.ln_b, b);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
+}
+
+template <int KS, int NW, bool ARGMAX, int KSL = 1>
+int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
+    const bool alias = KSL == 1 && gemv_mfma_alias(a);
+    if (gemv_mfma_line(a.K / KSL, NW, alias)) return launch_mfma_inst2<KS, NW, ARGMAX, KSL, true>(a, grid, alias, s);
+    return launch_mfma_inst2<KS, NW, ARGMAX, KSL, false>(a, grid, alias, s);
 }
 
 int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
@@ -1375,6 +1626,12 @@ int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
         return launch_mfma_inst<6, 16, false, 4>(a, grid, s);
     }
     const int steps = a.K / 32;
+    switch (lm_wpt_steps(a)) {  // lm_head, one wave per tile
+        case 12: return launch_lm_wpt<12>(a, grid, s);
+        case 24: return launch_lm_wpt<24>(a, grid, s);
+        case 32: return launch_lm_wpt<32>(a, grid, s);
+        default: break;
+    }
     if (a.epilogue == EPI_ARGMAX) {  // lm_head: 4 waves
         const int ks = (steps + 3) / 4;
         if (ks <= 3) return launch_mfma_inst<3, 4, true>(a, grid, s);
@@ -1522,6 +1779,10 @@ int gemv_plan(GemvArgs& a, int weight_type) {
         if (a.kslices > 1) {  // one tile per workgroup and slice
             a.rows_per_wave = 1;
             return ntiles;
+        }
+        if (lm_wpt_steps(a) > 0) {  // one wave per tile: every wave of a workgroup gets the same number of tiles
+            a.rows_per_wave = lm_wpt_tiles_per_wg();
+            return (ntiles + a.rows_per_wave - 1) / a.rows_per_wave;
         }
         static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
         int tpw = (ntiles + wgs - 1) / wgs;  // at most ~4 workgroups per CU for the widest matrices
