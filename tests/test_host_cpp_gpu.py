@@ -29,3 +29,29 @@ def test_cpp_host_generation_matches_oracle(name, seed, n_steps, tier):
     ids = np.array([int(t) for t in out.stdout.split()], dtype=np.uint64)
     ref = oracle.GPT(cfg, synth.make_weights(cfg, seed=seed, bf16=True)).generate_greedy(prompt, n_steps)
     assert np.array_equal(ids, ref), (ids, ref)
+
+
+@pytest.mark.parametrize("tier", ["ops", "model"])
+def test_cpp_host_reads_the_raw_weight_directory(tmp_path, tier):
+    """load_linear / load_layer_norm / load_embedding (src/main.zig:210-269) in the C++ host: the reference's raw
+    directory format written by weights_io.save_raw_dir (download_weights.py:57-64 layout); wrong sizes are errors."""
+    from zig_gpt2_amd import weights_io
+
+    cfg = synth.CONFIGS["tiny3"]
+    w = synth.make_weights(cfg, seed=41, bf16=True)
+    d = str(tmp_path / "raw")
+    weights_io.save_raw_dir(d, cfg, w)
+    prompt = synth.rand_tokens(411, 3, cfg.vocab_size)
+    args = [BIN, "tiny3", d, ",".join(str(int(t)) for t in prompt), "24"] + (["--model-tier"] if tier == "model" else [])
+    env = dict(os.environ, ZGPT2_STAGING_MB="64")
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    ids = np.array([int(t) for t in out.stdout.split()], dtype=np.uint64)
+    assert np.array_equal(ids, oracle.GPT(cfg, w).generate_greedy(prompt, 24))
+    # a truncated tensor file is refused (the reference's load_tensor would silently keep zeros)
+    f = os.path.join(d, "model-h1-mlp-c_fc-w")
+    with open(f, "r+b") as fh:
+        fh.truncate(os.path.getsize(f) - 4)
+    bad = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0 and "size does not match" in bad.stderr
+

@@ -7,7 +7,7 @@
 // portable synthetic generator (bit-identical to zig_gpt2_amd/synth.py), the prompt is a list of
 // token ids, and sampling is greedy argmax instead of the reference's time-seeded multinomial.
 //
-//   zgpt2_main <tiny|tiny3|nano-char|124M> <weight_seed> <tok,tok,...> <n_steps> [--model-tier]
+//   zgpt2_main <tiny|tiny3|nano-char|124M> <weight_seed | raw weight directory> <tok,tok,...> <n_steps> [--model-tier]
 // prints the tokens after every step on one line (prompt tokens included, main.zig:339-340).
 #include <cmath>
 #include <cstdint>
@@ -79,6 +79,35 @@ struct Weights {  // tensor order / seeds of zig_gpt2_amd/synth.py::tensor_specs
         h.resize(c.n_layer);
         for (size_t l = 0; l < c.n_layer; ++l)
             for (int s = 0; s < 12; ++s) h[l].t[s] = fill_normal(seed * 4096 + 16 + 16 * l + s, sizes[s], means[s], 0.02f);
+    }
+
+    // The reference's raw weight directory (load_linear / load_layer_norm / load_embedding, main.zig:210-269, which
+    // hard-code "models/124M/raw/"): one little-endian fp32 file per tensor, `model-<tf name with / -> ->`, Linear
+    // weights already [out, in] (download_weights.py:57-64).  Unlike load_tensor (ops.zig:318, short reads ignored) a
+    // file of the wrong size is an error.
+    static Buf read_tensor(const std::string& dir, const std::string& stem, size_t n) {
+        const std::string path = dir + "/model-" + stem;
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        Buf out(n);
+        const size_t got = fread(out.data(), sizeof(float), n, f);
+        const bool more = got == n && fgetc(f) != EOF;
+        fclose(f);
+        if (got != n || more) throw std::runtime_error(path + ": size does not match the config");
+        return out;
+    }
+    Weights(const GPTConfig& c, const std::string& dir) {
+        const size_t E = c.n_embed;
+        wte = read_tensor(dir, "wte", c.vocab_size * E);
+        wpe = read_tensor(dir, "wpe", c.context_size * E);
+        ln_f_g = read_tensor(dir, "ln_f-g", E);
+        ln_f_b = read_tensor(dir, "ln_f-b", E);
+        const char* stems[12] = {"ln_1-g", "ln_1-b", "attn-c_attn-w", "attn-c_attn-b", "attn-c_proj-w", "attn-c_proj-b",
+                                 "ln_2-g", "ln_2-b", "mlp-c_fc-w", "mlp-c_fc-b", "mlp-c_proj-w", "mlp-c_proj-b"};
+        const size_t sizes[12] = {E, E, 3 * E * E, 3 * E, E * E, E, E, E, 4 * E * E, 4 * E, 4 * E * E, E};
+        h.resize(c.n_layer);
+        for (size_t l = 0; l < c.n_layer; ++l)
+            for (int s = 0; s < 12; ++s) h[l].t[s] = read_tensor(dir, "h" + std::to_string(l) + "-" + stems[s], sizes[s]);
     }
 };
 
@@ -204,7 +233,7 @@ static std::vector<size_t> generate_model_tier(const GPTConfig& c, const Weights
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <tiny|tiny3|nano-char|124M> <seed> <tok,tok,...> <n_steps> [--model-tier]\n", argv[0]);
+        fprintf(stderr, "usage: %s <tiny|tiny3|nano-char|124M> <seed | raw weight dir> <tok,tok,...> <n_steps> [--model-tier]\n", argv[0]);
         return 2;
     }
     const std::string name = argv[1];
@@ -214,14 +243,16 @@ int main(int argc, char** argv) {
     else if (name == "nano-char") config = {65, 256, 6, 6, 384};
     else if (name == "124M") config = {50257, 1024, 12, 12, 768};  // main.zig:346
     else return 2;
-    const uint64_t seed = strtoull(argv[2], nullptr, 10);
+    const std::string wsrc = argv[2];  // digits: seed of the synthetic weights; anything else: a raw weight directory
+    const bool from_dir = wsrc.find_first_not_of("0123456789") != std::string::npos;
+    const uint64_t seed = from_dir ? 0 : strtoull(argv[2], nullptr, 10);
     std::vector<size_t> inputs;
     for (char* p = strtok(argv[3], ","); p; p = strtok(nullptr, ",")) inputs.push_back(strtoull(p, nullptr, 10));
     const size_t n_steps = strtoull(argv[4], nullptr, 10);
     const bool model_tier = argc > 5 && std::string(argv[5]) == "--model-tier";
     try {
         ops::check(zg_init(0));
-        Weights w(config, seed);
+        const Weights w = from_dir ? Weights(config, wsrc) : Weights(config, seed);
         std::vector<size_t> out;
         if (model_tier) {
             out = generate_model_tier(config, w, inputs, n_steps);
