@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256) void lm_head_wpt_kernel(const bf16_t* __restri
 
 // Which lm_head launches take the wave-per-tile kernel: the K values whose tile fits a wave's registers.
 inline int lm_wpt_steps(const GemvArgs& a) {
-    static const int off = getenv("ZGPT2_NO_LM_WPT") ? atoi(getenv("ZGPT2_NO_LM_WPT")) : 0;
+    const int off = getenv("ZGPT2_NO_LM_WPT") ? atoi(getenv("ZGPT2_NO_LM_WPT")) : 0;  // read per call: tests flip it between handles
     if (off || a.epilogue != EPI_ARGMAX || a.prologue != PRO_LAYERNORM || a.M < 2 || a.M > kMfmaRows || a.K % 32 != 0) return 0;
     const int ns = a.K / 32;
     return (ns == 12 || ns == 24 || ns == 32) ? ns : 0;
@@ -1584,7 +1584,7 @@ inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false, bool line
 }
 // full-line weight loads (LINE instantiations): whole pairs of 32-k steps and room for one 2-KiB slot per wave
 inline bool gemv_mfma_line(int K, int nw, bool alias_partial) {
-    static const int off = getenv("ZGPT2_NO_LINE_LOADS") ? atoi(getenv("ZGPT2_NO_LINE_LOADS")) : 0;
+    const int off = getenv("ZGPT2_NO_LINE_LOADS") ? atoi(getenv("ZGPT2_NO_LINE_LOADS")) : 0;  // read per call: tests flip it between handles
     return !off && !alias_partial && K % 64 == 0 && gemv_mfma_lds(K, nw, false, true) <= 160 * 1024;
 }
 
