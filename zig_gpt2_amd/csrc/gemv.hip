@@ -809,8 +809,19 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane % LPR, rsub = lane / LPR;
-    const int Kq = K >> 2, nchq = Kq >> 3;
-    const WT* W = reinterpret_cast<const WT*>(Wv) + (size_t)wave * Kq;
+    // The wave's share of K.  bf16 rows of whole 128-byte lines (K % 64 == 0): whole lines per wave — 7, 6, 6, 6 of
+    // the 25 at K = 1600 instead of four times 6.25, whose quarters begin mid-line and make every wave touch the
+    // boundary lines of its neighbours as well (31 line touches per row instead of 25).
+    int kbeg, nchq;
+    if (sizeof(WT) == 2 && (K & 63) == 0 && ((K >> 6) & 3) != 0 && (((K >> 6) >> 2) + 1) * 8 <= LPR * CPL) {
+        const int lines = K >> 6, base = lines >> 2, rem = lines & 3;
+        kbeg = (wave * base + min(wave, rem)) * 64;
+        nchq = (base + (wave < rem ? 1 : 0)) * 8;
+    } else {
+        kbeg = wave * (K >> 2);
+        nchq = K >> 5;
+    }
+    const WT* W = reinterpret_cast<const WT*>(Wv) + kbeg;
     const int row0 = blockIdx.x * ROWS;
     Raw<WT> wq[NP][CPL];
 #pragma unroll
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
     W8 xr[CPL], gr[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
-        const size_t off = (size_t)wave * Kq + (size_t)min(lr + LPR * i, nchq - 1) * 8;
+        const size_t off = (size_t)kbeg + (size_t)min(lr + LPR * i, nchq - 1) * 8;
         xr[i] = load_x8(xin + off);
         gr[i] = load_x8(ln_g + off);
     }
