@@ -26,8 +26,6 @@ namespace zg {
 
 namespace {
 
-__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // One 4-byte load per 128-byte line: the line lands in this XCD's L2, the value is discarded.  A plain load: the
 // compiler waits for it only where the value is consumed (a `volatile` one is waited for on the spot).
 __device__ __forceinline__ unsigned touch(const char* p) { return *reinterpret_cast<const unsigned*>(p); }
