@@ -289,8 +289,13 @@ def main():
     ]
     table = []
     for which, name, n_launch, nbytes in classes:
+        os.environ["ZGPT2_TIME_CYCLE"] = "0"
         us, _ = model.time_kernel(which, 256)
+        os.environ["ZGPT2_TIME_CYCLE"] = "1"  # walk the layers: weights / KV from the memory side, as in the real step
+        us_cold, _ = model.time_kernel(which, 256)
+        os.environ["ZGPT2_TIME_CYCLE"] = "0"
         table.append({"class": name, "launches_per_token": n_launch, "avg_launch_us": round(us, 3),
+                      "avg_launch_us_layers_walked": round(us_cold, 3),
                       "algorithmic_bytes_per_launch": int(nbytes), "GBps": round(nbytes / us / 1e3, 1),
                       "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_token": round(us * n_launch, 2)})
     tot_us = sum(r["us_per_token"] for r in table)
@@ -390,7 +395,9 @@ def main():
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
             "share_of_token_time": dom["share_of_token_time"],
             "how": "the kernel class with the largest share of the decode-step time; duration = HIP events on the launch "
-                   "stream around a hipGraph chain of that kernel (launch boundary included), measured in this run",
+                   "stream around a hipGraph chain of that kernel (launch boundary included), measured in this run; "
+                   "kernel_classes also lists avg_launch_us_layers_walked: the same chain walking the layers, i.e. with "
+                   "weights / KV coming from the memory side as in the real step (lm_head has one matrix: identical)",
         },
         "kernel_classes": table,
         "roofline_lm_head": {"kernel": lm["class"], "achieved": lm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
