@@ -16,7 +16,7 @@ w = {t: synth.round_bf16(rng.standard_normal(int(np.prod(sh)), dtype=np.float32)
      for t, sh, mu, _ in synth.tensor_specs(cfg)}
 prompts = [synth.rand_tokens(900 + i, 3, cfg.vocab_size) for i in range(B)]
 ref = None
-for k in (1, 2, 4, 8, 16, 1):
+for k in (1, 2, 4, 8, 16, 32, 1):
     os.environ["ZGPT2_GRAPH_STEPS"] = str(k)
     t0 = time.perf_counter()
     m = gpt.GPT(cfg, batch=B)

@@ -766,7 +766,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     {   // decode steps per graph in the generate loop: a graph launch costs ~7 us of idle queue (124M: 224.8 us per token
         // with 1 step per graph, 220.4 with 2 / 4, 218.3 with 8, 219.5 with 16)
         const int k = env_int("ZGPT2_GRAPH_STEPS", 8);
-        g->graph_steps = (k == 2 || k == 4 || k == 8 || k == 16) ? (size_t)k : 1;
+        g->graph_steps = (k == 2 || k == 4 || k == 8 || k == 16 || k == 32 || k == 64) ? (size_t)k : 1;
     }
     {   // every decode graph is captured and instantiated here, not on the first forward that needs it
         int st = setup_prefetcher(g);
