@@ -75,7 +75,9 @@ struct zg_gpt {
     int pf_njobs;
     bool pf_on;
     bool pf_ran;      // a prefetcher was launched by the last generate call
-    bool pf_stalled;  // one left on its idle limit (no concurrency with the decode stream here): not launched again
+    bool pf_stalled;  // one left on its idle limit (no concurrency with the decode stream, or a host hiccup): sitting out
+    int pf_strikes;   // idle-limit exits so far; the third one is final
+    int pf_sit_out;   // generate calls left before a stalled prefetcher is tried again
     hipStream_t pf_stream;
     hipEvent_t pf_ev_main, pf_ev_side;
 };
@@ -506,6 +508,7 @@ int env_int(const char* name, int dflt) {
 // BEFORE the graphs are captured (the decode kernels get the progress counter as an argument).
 int setup_prefetcher(zg_gpt* g) {
     g->pf_on = g->pf_ran = g->pf_stalled = false;
+    g->pf_strikes = g->pf_sit_out = 0;
     g->pf_stream = nullptr;
     g->pf_ev_main = g->pf_ev_side = nullptr;
     // Default: only where it was measured to pay — one sequence and Linears of a few MB (GPT-2 124M: 241 -> 224 us per
@@ -513,9 +516,10 @@ int setup_prefetcher(zg_gpt* g) {
     const bool small = g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
     const int want = env_int("ZGPT2_PREFETCH", small ? 1 : 0);
     if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || ctx().stream == nullptr) return ZG_OK;
+    if (g->pf_njobs > 255) return ZG_OK;  // the progress word counts launches in 8 bits (n_layer >= 51): no prefetcher, not an error
     std::vector<PfJob> jobs;
     ZG_TRY(enqueue_step(g, true, (int)g->cfg.context_size, nullptr, nullptr, -1, 0, &jobs));
-    ZG_REQUIRE((int)jobs.size() == g->pf_njobs && g->pf_njobs <= 255, ZG_ERR_ARG, "prefetcher: %zu launches per step", jobs.size());
+    ZG_REQUIRE((int)jobs.size() == g->pf_njobs, ZG_ERR_ARG, "prefetcher: %zu launches per step", jobs.size());
     ZG_HIP(hipMemcpy(g->pf_jobs, jobs.data(), jobs.size() * sizeof(PfJob), hipMemcpyHostToDevice));
     int least = 0, greatest = 0;
     ZG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -549,10 +553,19 @@ int pf_start(zg_gpt* g, size_t last_T, hipStream_t s) {
         ZG_HIP(hipStreamSynchronize(g->pf_stream));
         unsigned why[8];
         ZG_HIP(hipMemcpy(why, g->pf_ctl->exit_reason, sizeof(why), hipMemcpyDeviceToHost));
-        for (unsigned w : why) g->pf_stalled |= w == 2u;
+        bool idle_exit = false;
+        for (unsigned w : why) idle_exit |= w == 2u;
         g->pf_ran = false;
+        if (idle_exit) {  // a strike, not a verdict: one slow host moment inside a generate loop produces the same exit
+            g->pf_stalled = true;
+            ++g->pf_strikes;
+            g->pf_sit_out = env_int("ZGPT2_PF_REARM", 8);  // generate calls without it before the next try
+        }
     }
-    if (g->pf_stalled) return ZG_OK;
+    if (g->pf_stalled) {
+        if (g->pf_strikes >= 3 || g->pf_sit_out-- > 0) return ZG_OK;
+        g->pf_stalled = false;  // try again
+    }
     ZG_HIP(hipMemsetAsync(g->pf_ctl, 0, sizeof(PfCtl), g->pf_stream));
     ZG_HIP(hipEventRecord(g->pf_ev_side, g->pf_stream));
     ZG_HIP(hipStreamWaitEvent(s, g->pf_ev_side, 0));
@@ -853,6 +866,16 @@ int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len) {
 
 int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes) {
     ZG_REQUIRE(g && device_ptr && bytes, ZG_ERR_ARG, "weight_arena: null argument");
+    // The folded-LayerNorm vectors (c2 / c3) live inside the region handed out here.  A sender has to hold valid
+    // ones before its bytes are copied, and a receiver must re-derive them from whatever lands in the region — also a
+    // receiver that has run before (its flag would still say "folded").  So: fold now if needed (sender side: a few
+    // small launches, drained), and mark the vectors stale for the next forward (receiver side: one re-fold).
+    if (!g->ln_folded) {
+        ZG_TRY(require_init());
+        ZG_TRY(ensure_ln_folded(g, ctx().stream));
+        ZG_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    g->ln_folded = false;
     *device_ptr = g->arena;
     *bytes = g->weight_region_bytes;
     return ZG_OK;
@@ -1028,6 +1051,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
         ZG_TRY(enqueue_prefill(g, first, false, s));
     }
     ZG_TRY(ensure_ln_folded(g, s));
+    if (!(g->flags & ZG_GPT_NO_GRAPH) && s != nullptr && g->graph_stream != s) ZG_TRY(capture_all(g, s));  // before the prefetcher starts its idle clock
     ZG_TRY(pf_start(g, n_steps, s));
     int rs = ZG_OK;
     const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;

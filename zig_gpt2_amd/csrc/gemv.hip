@@ -1581,6 +1581,14 @@ inline int lm_wpt_tiles_per_wg() {  // a multiple of the four waves
 template <int NS>
 int launch_lm_wpt(const GemvArgs& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)3 * kMfmaRows * (2 * a.K + 16) + 4 * kMfmaRows * sizeof(Best) + 4 * 4096;
+    if (lds > 64 * 1024) {  // K = 1024 (NS = 32): 66,176 B — opt in once per instantiation, like every other launcher here
+        static bool raised = false;
+        if (!raised) {
+            ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_head_wpt_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL((lm_head_wpt_kernel<NS>), dim3(grid), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K,
                        a.M, a.rows_per_wave, a.ln_g, a.ln_b, a);
     ZG_HIP(hipGetLastError());

@@ -106,6 +106,7 @@ CONFIGS = {
     "tiny3": GPTConfig(131, 48, 3, 3, 192),  # test-only, odd sizes
     "xl-slice": GPTConfig(1031, 96, 2, 25, 1600),  # test-only: GPT-2 XL's layer shapes (E = 1600, 25 heads), 2 layers
     "max-slice": GPTConfig(515, 72, 1, 32, 2048),  # test-only: the widest supported model (4 E = 8192), 1 layer
+    "medium-slice": GPTConfig(521, 80, 2, 16, 1024),  # test-only: GPT-2 medium's layer shapes (E = 1024, 16 heads), 2 layers
 }
 
 BLOCK_TENSORS = [
