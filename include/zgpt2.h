@@ -133,6 +133,9 @@ int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_n
 /* Diagnostic: number of matrix-core GEMM launches so far in this process (tests assert which path a
  * Linear took; no reference counterpart). */
 unsigned long long zg_debug_gemm_launches(void);
+/* Diagnostic: shader-clock stamps {count, start, end} of workgroup 0 / wave 0 of the last GEMM launched with
+ * ZGPT2_GEMM_DBG bit 256 (tools/microbench/gemm_bench.cpp: cycles vs wall time = the clock the chip ran at). */
+int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words);
 int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len);
 
 /* ------------------------------------------------------------------ model tier: src/main.zig */

@@ -367,6 +367,7 @@ int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_n
 }
 
 unsigned long long zg_debug_gemm_launches(void) { return gemm_mfma_launch_count(); }
+int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words) { return gemm_s4_stamps(out, n_words); }
 
 int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len) {
     ZG_TRY(require_init());

@@ -24,6 +24,7 @@
 //     first K-steps land while the current tile's epilogue runs.
 //   * XCD-aware tile order: each XCD (private 4-MiB L2) owns a contiguous range of a column-banded order.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -532,7 +533,20 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     ZG_REQUIRE(pl.lda % 8 == 0 && pl.ldb % 8 == 0 && pl.lda >= K && pl.ldb >= K, ZG_ERR_UNSUPPORTED, "gemm: lda=%d ldb=%d", pl.lda, pl.ldb);
     const int cq = out_bf16 ? 8 : 4;  // output leaves in 16-byte pieces
     ZG_REQUIRE(N % cq == 0 && ldc >= N && ldc % cq == 0, ZG_ERR_UNSUPPORTED, "gemm: N=%d ldc=%d must be multiples of %d", N, ldc, cq);
-    ZG_REQUIRE((size_t)M * pl.lda < (1u << 30) && (size_t)N * pl.ldb < (1u << 30), ZG_ERR_SHAPE, "gemm: operand over 2 GiB");
+    ZG_REQUIRE((size_t)N * pl.ldb < (1u << 30), ZG_ERR_SHAPE, "gemm: B operand over 2 GiB");
+    if ((size_t)M * pl.lda >= (1u << 30)) {
+        // The A operand is addressed through a 32-bit buffer descriptor: a taller A goes in row chunks (whole tiles,
+        // under 2 GiB each) — e.g. the mlp c_proj of a long fp32-weight prefill, whose plane rows are 12 E wide.
+        const int rows = (int)((((size_t)1 << 30) - 1) / (size_t)pl.lda) / 256 * 256;
+        ZG_REQUIRE(rows >= 256, ZG_ERR_SHAPE, "gemm: lda=%d too wide", pl.lda);
+        const size_t esz = out_bf16 ? 2 : 4;
+        for (int r0 = 0; r0 < M; r0 += rows) {
+            const int mc = M - r0 < rows ? M - r0 : rows;
+            ZG_TRY(launch_gemm_planes(A + (size_t)r0 * pl.lda, B, bias, reinterpret_cast<char*>(C) + (size_t)r0 * ldc * esz, mc, N, pl, ldc,
+                                      gelu, out_bf16, s));
+        }
+        return ZG_OK;
+    }
     // tile width: the one that wastes fewer CU-rounds (M = 8192, N = 3072: 512 tiles of 256 x 192 = 2.0 per CU
     // against 384 tiles of 256 x 256 = two rounds with half the chip idle in the second)
     const int bn_env = getenv("ZGPT2_GEMM_BN") ? atoi(getenv("ZGPT2_GEMM_BN")) : 0;
@@ -543,6 +557,8 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     int bn = cost(192) < cost(256) ? 192 : 256;
     if (bn_env == 192 || bn_env == 256) bn = bn_env;
     ++g_gemm_launches;
+    if (const char* kk = getenv("ZGPT2_GEMM_KERNEL"); kk && !strcmp(kk, "s4"))
+        return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, bn, s);
     return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
                      : launch_p8_bn<256>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
 }

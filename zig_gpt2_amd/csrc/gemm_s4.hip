@@ -1,0 +1,575 @@
+// gemm_s4.hip — the large-batch Linear on the CDNA4 matrix cores, second generation:
+//   C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (optionally GELU), bf16 operands, fp32 accumulate.
+// Linear.forward of the reference (src/ops.zig:21-46: cblas_sgemm RowMajor/NoTrans/Trans, bias pre-filled) for
+// M >> 1: both operands K-contiguous, exactly ops.Linear's layouts (x is [M, in], weight is [out, in]).
+//
+// Structure (what the measurements of round 3 asked for, tools/microbench/dma_intake.hip):
+//   * FOUR waves per workgroup, one per SIMD, each with the whole 512-register file: a 256 x BN tile (BN = 192 or
+//     256) as 2 x 2 wave tiles of 128 x BN/2, v_mfma_f32_32x32x16_bf16 (twice the flops per operand register of the
+//     16x16x32 form), operands SWAPPED (A operand = weight rows) so that a lane's accumulator registers are
+//     runs of 4 consecutive output columns of one output row.
+//   * Every wave runs ONE software-pipelined instruction stream: the fragment reads of k-slice j + 1 are issued
+//     in front of the MFMAs of k-slice j (two fragment buffers), the LDS-DMA pieces (buffer_load ... lds) of the
+//     K-step two ahead are spread between the MFMAs, and the workgroup meets at only TWO barriers per K-step
+//     (the first-generation kernel: eight, each behind an exposed fragment-read latency).
+//   * LDS: two K-step slots; a K-step is three DMA units — A half 0 (rows 0-63 of every wave row), B, A half 1 —
+//     consumed as two phases of four k-slices (half 0 x B, half 1 x B), so that a unit is free, and its
+//     replacement in flight, more than a K-step before it is needed.
+//   * Persistent: <= 256 workgroups walk XCD-contiguous ranges of a column-banded tile order; the DMA stream
+//     continues across tile boundaries (the next tile's first K-steps land under the epilogue).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "zg_kernels.h"
+
+namespace zg {
+
+__device__ unsigned long long g_s4_stamps[1 + 2 * 256 + 16];  // diagnostic (dbg bit 256): shader-clock {start, end} of every workgroup's wave 0
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16v;
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+
+// gelu(x) = x / (1 + exp(-2u)), u = x * 0.7978845608 * (1 + 0.044715 x^2)  (src/ops.zig:225); the -2 log2(e)
+// factor is folded into the polynomial so that the exponential is a bare v_exp_f32
+__device__ __forceinline__ float gelu1(float x) {
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
+    const float arg = x * fmaf(x * x, k2, k1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+}
+
+__device__ __forceinline__ f32x2v gelu2(f32x2v x) {
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
+    const f32x2v p = __builtin_elementwise_fma(x * x, f32x2v{k2, k2}, f32x2v{k1, k1});
+    const f32x2v arg = x * p;
+    const f32x2v d = f32x2v{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)} + f32x2v{1.0f, 1.0f};
+    return x * f32x2v{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
+template <int NT_>
+struct S4 {
+    static constexpr int NT = NT_;              // 32-column MFMA tiles per wave: 3 or 4
+    static constexpr int BM = 256, BN = 64 * NT;
+    static constexpr int A_SLOT = 256 * 128, B_SLOT = BN * 128;
+    static constexpr int A_OFF = 0, B_OFF = 2 * A_SLOT;  // [A slot 0][A slot 1][B slot 0][B slot 1]
+    static constexpr int LDS = 2 * A_SLOT + 2 * B_SLOT;  // 112 / 128 KiB
+    static constexpr int PB = BN / 32;          // B pieces (8 rows x 128 B) per wave per K-step: 6 or 8
+    static constexpr int W3 = 8 + PB;           // pieces that may still be in flight when A half 1 of this K-step must have landed
+};
+
+#define ZG_SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ lds_ptr_t to_lds(unsigned byte_addr) { return (lds_ptr_t)(size_t)byte_addr; }
+
+__device__ __forceinline__ void tile_of(int idx, int tiles_m, int tiles_n, int gw, int& tm, int& tn) {
+    const int band = idx / (tiles_m * gw), full = tiles_n / gw;
+    if (band < full) {
+        const int r = idx - band * tiles_m * gw;
+        tm = r / gw;
+        tn = band * gw + r % gw;
+    } else {
+        const int w = tiles_n - full * gw, r = idx - full * tiles_m * gw;
+        tm = r / w;
+        tn = full * gw + r % w;
+    }
+}
+
+template <int I>
+using Ic = std::integral_constant<int, I>;
+
+struct Ahead {  // where a K-step of the DMA stream comes from
+    unsigned baseA, baseB, kbA, kbB;
+};
+
+// Fragment reads are hand-issued so that they stay where they are written (nothing orders the compiler's own LDS loads
+// against s_barrier or an LDS-DMA).  J = 4 h + ks: A half h, k-slice ks; I: 32-row tile.
+template <int NT, int X, int J, int I>
+__device__ __forceinline__ void read_frag_a(bf16x8& f, const unsigned (&a_addr)[4]) {
+    using P = S4<NT>;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a_addr[J & 3]), "i"(X * P::A_SLOT + (J >> 2) * 16384 + I * 4096));
+}
+template <int NT, int X, int J, int I>
+__device__ __forceinline__ void read_frag_b(bf16x8& f, const unsigned (&b_addr)[4]) {
+    using P = S4<NT>;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(b_addr[J & 3]), "i"(X * P::B_SLOT + I * 4096));
+}
+
+template <int NT, int X>
+__device__ __forceinline__ void read_b_all(bf16x8 (&fb)[4][NT], const unsigned (&b_addr)[4]) {
+    using P = S4<NT>;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[ks][j]) : "v"(b_addr[ks]), "i"(X * P::B_SLOT + j * 4096));
+}
+
+template <int NT, bool GELU, bool OUT_BF16, int ABL>
+__global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         const float* __restrict__ bias, void* __restrict__ C, int M, int N,
+                                                         GemmPlanes pl, int ldc, int tiles_m, int tiles_n, int gw, int dbg) {
+    using P = S4<NT>;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)lds;
+
+    // ---- this workgroup's tiles: XCD x = bid % 8 owns a contiguous range of the banded order
+    const int n_tiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
+    const int nx = G < 8 ? G : 8;
+    const int xcd = bid % nx, loc = bid / nx;
+    const int gx = G / nx + (xcd < G % nx ? 1 : 0);
+    const int q8 = n_tiles / nx, r8 = n_tiles % nx;
+    const int t_begin = xcd * q8 + min(xcd, r8), t_end = t_begin + q8 + (xcd < r8 ? 1 : 0);
+    int idx = t_begin + loc;
+    if (idx >= t_end) return;
+    const bool stamp = (dbg & 256) && wave == 0 && bid < 256;
+    unsigned long long t_start = 0;
+    if (stamp) t_start = __builtin_readcyclecounter();
+
+    // ---- DMA sources.  A piece = 8 unit rows x 128 B, written lane-linearly (lane -> row lane / 8, 16-B position
+    // lane % 8); position p of LDS row R holds source chunk p ^ ((R >> 1) & 7) (the swizzle the fragment reads undo).
+    // A wave issues pieces q = wave + 4 i of every unit; (R >> 1) & 7 = ((q & 1) << 2) | (lane >> 4) does not depend on i.
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * pl.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * pl.ldb * 2), 0x00020000);
+    const unsigned lda2 = (unsigned)pl.lda * 2u, ldb2 = (unsigned)pl.ldb * 2u;
+    const int csrc = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+    const unsigned relA = (unsigned)(wave * 8 + (lane >> 3)) * lda2 + (unsigned)csrc * 16u;
+    const unsigned relB = (unsigned)(wave * 8 + (lane >> 3)) * ldb2 + (unsigned)csrc * 16u;
+
+    // ---- fragment reads: lane -> row lane & 31 of a 32-row MFMA tile, k-chunk 2 ks + (lane >> 5) of the row's 8
+    const int l31 = lane & 31, hh = lane >> 5;
+    const unsigned swz = (unsigned)((hh ^ ((l31 >> 1) & 7)) << 4);
+    const unsigned a_addr0 = lds_base + P::A_OFF + (unsigned)(wr * 64 + l31) * 128u + swz;
+    const unsigned b_addr0 = lds_base + P::B_OFF + (unsigned)(wc * (P::BN / 2) + l31) * 128u + swz;
+    const unsigned a_addr[4] = {a_addr0, a_addr0 ^ 32u, a_addr0 ^ 64u, a_addr0 ^ 96u};
+    const unsigned b_addr[4] = {b_addr0, b_addr0 ^ 32u, b_addr0 ^ 64u, b_addr0 ^ 96u};
+
+    // ---- K-steps walk the plane pairs: step kt = pair * kpp + kk multiplies A plane pa[pair] with B plane pb[pair]
+    const int kpp = pl.kpp;
+    int pi_cur = 0, kk_cur = 0;
+    int tm, tn;
+    tile_of(idx, tiles_m, tiles_n, gw, tm, tn);
+    const unsigned strideA = 256u * lda2, strideB = (unsigned)P::BN * ldb2;
+    unsigned curA = (unsigned)tm * strideA, curB = (unsigned)tn * strideB;
+    int m0 = tm * 256, n0 = tn * P::BN;
+    constexpr unsigned kOob = 0x80000000u;  // tile base of "no next tile": every lane out of range -> zero fill
+    unsigned nxtA = kOob, nxtB = kOob;
+    int nidx = idx + gx, ntm = 0, ntn = 0;
+    if (nidx < t_end) {
+        tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
+        nxtA = (unsigned)ntm * strideA;
+        nxtB = (unsigned)ntn * strideB;
+    }
+    auto ahead = [&](int d) {  // K-step t + d of the stream (d <= 2 <= kpp); runs on into the next tile
+        int kk = kk_cur + d, pi = pi_cur;
+        if (kk >= kpp) {
+            kk -= kpp;
+            ++pi;
+        }
+        const bool in_cur = pi < pl.npairs;
+        if (!in_cur) pi = 0;
+        const unsigned pa = (pl.pa_bits >> (4 * pi)) & 15u, pb = (pl.pb_bits >> (4 * pi)) & 15u;
+        Ahead s;
+        s.kbA = (pa * (unsigned)kpp + (unsigned)kk) * 128u;
+        s.kbB = (pb * (unsigned)kpp + (unsigned)kk) * 128u;
+        s.baseA = in_cur ? curA : nxtA;
+        s.baseB = in_cur ? curB : nxtB;
+        return s;
+    };
+    // piece i (0..3) of A half h of stream position s -> slot X
+    // diagnostic ablations, compile time (ZGPT2_S4_ABL; timing only, wrong results): 1 no DMA, 2 no barriers, 4 no fragment reads,
+    // 8 no waits on the fragment reads
+    constexpr bool abl_dma = ABL & 1, abl_bar = ABL & 2, abl_rd = ABL & 4, abl_lgkm = ABL & 8;
+    auto dma_a = [&](int X, int h, int i, const Ahead& s) {
+        if constexpr (abl_dma) return;
+        const unsigned rowd = (unsigned)((i >> 1) * 128 + h * 64 + (i & 1) * 32);
+        const unsigned dst = lds_base + P::A_OFF + X * P::A_SLOT + h * 16384 + (wave + 4 * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, to_lds(dst), 16, relA, s.baseA + rowd * lda2 + s.kbA, 0, 0);
+    };
+    auto dma_b = [&](int X, int i, const Ahead& s) {
+        if constexpr (abl_dma) return;
+        const unsigned dst = lds_base + P::B_OFF + X * P::B_SLOT + (wave + 4 * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, to_lds(dst), 16, relB, s.baseB + (unsigned)(i * 32) * ldb2 + s.kbB, 0, 0);
+    };
+    f32x16v acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // Fragments.  A: two buffers by step parity (2 tiles of 32 rows, one k-slice).  B: the WHOLE K-step of this wave's
+    // columns (4 k-slices x NT tiles), two buffers by K-step parity — B is read from LDS once per K-step (both
+    // phases multiply the same B fragments), during steps 3..6 of the K-step before.
+    bf16x8 fa[2][2], fb[2][4][NT];
+
+    auto bar = [&]() {
+        ZG_SB();
+        if constexpr (!abl_bar) __builtin_amdgcn_s_barrier();
+        ZG_SB();
+    };
+    // all B fragments + the A fragments of step 0 of the K-step in slot X (kernel start: nothing else is in flight)
+    auto read_kstep_head = [&](auto XT) {
+        constexpr int X = decltype(XT)::value;
+        read_b_all<NT, X>(fb[X], b_addr);
+        read_frag_a<NT, X, 0, 0>(fa[0][0], a_addr);
+        read_frag_a<NT, X, 0, 1>(fa[0][1], a_addr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ZG_SB();
+    };
+    // End of a tile: the fragments of the next tile's first K-step (slot X) are in flight.  Registers written by a hand-issued
+    // ds_read must not be moved by the compiler before the data has landed, and the epilogue's register pressure makes it
+    // move things: wait for them here and hand them back to the compiler as NEW values (the empty statements), so that
+    // whatever it does with them happens behind the wait.
+    auto settle = [&](auto XT) {
+        constexpr int X = decltype(XT)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[X][ks][j]));
+        asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]));
+        ZG_SB();
+    };
+
+    Ahead s1, s2;  // stream positions t + 1 / t + 2 of the current K-step t
+    // One step = one k-slice (16 of K) of one phase: 2 x NT MFMAs, and behind each MFMA at most ONE other item
+    // (a fragment read or a DMA piece: two ds_read_b128 in one MFMA shadow do not fit — tools/microbench/mfma_lds.hip).
+    // J = 4 h + ks.  Per K-step t (slot X):
+    //   steps 0-2   DMA: B of K-step t + 2 -> slot X, A half 1 of K-step t + 1 -> slot X ^ 1
+    //   step 3      barrier 1 (A half 0 of slot X read out; A half 1 of t, B and A half 0 of t + 1 landed)
+    //   steps 3-6   DMA: A half 0 of K-step t + 2 -> slot X (one piece per step); B fragments of K-step t + 1 -> registers
+    //   step 7      barrier 2 (A half 1 of slot X, B of slot X ^ 1 read out)
+    auto step = [&](auto XT, auto JT) {
+        constexpr int X = decltype(XT)::value, J = decltype(JT)::value;
+        constexpr int h = J >> 2, ks = J & 3, cb = J & 1, nb = cb ^ 1;
+        constexpr int NW0 = P::PB + 4;                       // pieces of steps 0-2: 10 or 12
+        constexpr int n0 = (NW0 + 2) / 3, n1 = (NW0 - n0 + 1) / 2, n2 = NW0 - n0 - n1;  // 4,3,3 / 4,4,4
+        constexpr int nd = J == 0 ? n0 : J == 1 ? n1 : J == 2 ? n2 : J <= 6 ? 1 : 0;
+        constexpr int p0 = J == 0 ? 0 : J == 1 ? n0 : J == 2 ? n0 + n1 : 0;
+        constexpr bool b_reads = J >= 3 && J <= 6;           // this step carries NT B reads (k-slice J - 3 of K-step t + 1)
+        constexpr bool prev_b = J >= 4 && J <= 7;            // ... and so did the step before
+        // Order of a step's LDS reads (they return in order): [A tile 0, A tile 1] of the next step, with the NT B reads
+        // between them in steps 3-6 — behind MFMAs 0 .. NT + 1; the step's DMA pieces follow (steps 0-2: several).
+        constexpr int lenp = prev_b ? NT + 2 : 2;            // reads the step before issued; its A tile 1 was the last one
+        constexpr int mine = b_reads ? NT : 2;               // reads this step has issued before its MFMA NT
+        if constexpr (J == 3) {  // barrier 1: A half 0 of this slot is read out (the two reads of step 2 were its last)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (P::PB == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            bar();
+        }
+        if constexpr (J == 7) {  // barrier 2: A half 1 of this slot and B of the other are read out (step 6 issued the last reads)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (P::PB == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            bar();
+        }
+        // (Fragment reads run on across the end of a tile — the next tile's first K-step is in LDS by then; the tile loop
+        // waits for them before the epilogue, see there.)
+        auto gap = [&](auto MT) {  // the one item behind MFMA m
+            constexpr int m = decltype(MT)::value;
+            constexpr int JN = (J + 1) & 7, XN = (J == 7) ? (X ^ 1) : X;
+            // where the next step's A tile 1 is read: last, behind the B reads — except in step 6, whose reads must ALL be
+            // back before barrier 2 (they are the last ones of A half 1): the A tiles lead there
+            constexpr int a1_gap = (b_reads && J != 6) ? NT + 1 : 1;
+            constexpr int b_gap0 = J == 6 ? 2 : 1;           // first of the NT gaps that carry the B reads
+            constexpr int d_gap0 = b_reads ? NT + 2 : 2;     // first gap that carries a DMA piece
+            ZG_SB();
+            if constexpr (m == 0) {
+                if constexpr (J == 0) s2 = ahead(2);
+                if constexpr (!abl_rd) read_frag_a<NT, XN, JN, 0>(fa[nb][0], a_addr);
+            } else if constexpr (m == a1_gap) {
+                if constexpr (!abl_rd) read_frag_a<NT, XN, JN, 1>(fa[nb][1], a_addr);
+            } else if constexpr (b_reads && m >= b_gap0 && m < b_gap0 + NT) {
+                if constexpr (!abl_rd) read_frag_b<NT, X ^ 1, J - 3, m - b_gap0>(fb[X ^ 1][J - 3][m - b_gap0], b_addr);
+            } else if constexpr (m >= d_gap0 && m - d_gap0 < nd) {
+                constexpr int d = m - d_gap0;
+                if constexpr (J <= 2) {
+                    constexpr int p = p0 + d;
+                    if constexpr (p < P::PB) dma_b(X, p, s2);         // B of K-step t + 2 -> this slot
+                    else dma_a(X ^ 1, 1, p - P::PB, s1);              // A half 1 of K-step t + 1 -> other slot
+                } else
+                    dma_a(X, 0, J - 3, s2);                            // A half 0 of K-step t + 2 -> this slot
+            }
+            ZG_SB();
+        };
+        auto mma = [&](auto MT) {
+            constexpr int m = decltype(MT)::value, i = m / NT, j = m % NT;
+            // A operands: tile 0 was the FIRST read of the step before, tile 1 its LAST (steps 3 and 7 start behind lgkmcnt(0))
+            if constexpr (!abl_lgkm && J != 3 && J != 7) {
+                if constexpr (m == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(lenp - 1) : "memory");
+                if constexpr (m == NT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(mine) : "memory");
+                if constexpr (m == 0 || m == NT) ZG_SB();
+            }
+            acc[h * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[X][ks][j], fa[cb][i], acc[h * 2 + i][j], 0, 0, 0);
+            gap(MT);
+        };
+        mma(Ic<0>{});
+        mma(Ic<1>{});
+        mma(Ic<2>{});
+        mma(Ic<3>{});
+        mma(Ic<4>{});
+        mma(Ic<5>{});
+        if constexpr (NT == 4) {
+            mma(Ic<6>{});
+            mma(Ic<7>{});
+        }
+    };
+    auto kstep = [&](auto XT) {
+        step(XT, Ic<0>{});
+        step(XT, Ic<1>{});
+        step(XT, Ic<2>{});
+        step(XT, Ic<3>{});
+        step(XT, Ic<4>{});
+        step(XT, Ic<5>{});
+        step(XT, Ic<6>{});
+        step(XT, Ic<7>{});
+        s1 = s2;
+    };
+
+    // ---- epilogue of one tile, straight from the registers: lane (l31, hh) holds output row l31 of each 32 x 32
+    // tile and columns 8 g + 4 hh + {0..3} (register 4 g + e).  bf16: v_permlane32_swap makes 8 consecutive
+    // columns (16 B) per lane out of the two half-waves' runs of 4.
+    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    auto epilogue = [&]() {
+        if (dbg & 4) {  // diagnostic: no epilogue at all
+            float tsum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tsum += acc[i][j][r];
+                        acc[i][j][r] = 0.0f;
+                    }
+            if (tsum == 1.2345e33f) reinterpret_cast<float*>(C)[0] = tsum;
+            return;
+        }
+        int lane_e = lane;  // opaque copy: nothing derived from it can be hoisted into (and kept across) the main loop
+        asm volatile("" : "+v"(lane_e));
+        const int l31e = lane_e & 31, hhe = lane_e >> 5;
+        // Stores go through a buffer descriptor: a row past M lies past the descriptor's end and a column past N gets an
+        // out-of-range offset, so the hardware drops them — no exec masking, one straight block of code per tile.
+        const __amdgpu_buffer_rsrc_t rc =
+            __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)((size_t)M * ldc * ESZ), 0x00020000);
+        const f32x16v zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const unsigned no_store = (dbg & 1) ? 0xFFFFFFFFu : 0u;
+        // every bias value of the tile first: a load behind a store would make the compiler drain the stores (vmcnt(0))
+        f32x4v bva[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int col = n0 + wc * (P::BN / 2) + j * 32 + 8 * g + 4 * hhe;
+                col = min(col, N - 4);  // columns past N are dropped at the store; keep the address valid
+                bva[j][g] = bias != nullptr ? *reinterpret_cast<const f32x4v*>(bias + col) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int gcol = n0 + wc * (P::BN / 2) + j * 32;
+            const f32x4v(&bv)[4] = bva[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned row_off = (unsigned)(m0 + wr * 128 + i * 32 + l31e) * (unsigned)(ldc * ESZ);
+                const f32x16v av = acc[i][j];
+                acc[i][j] = zero16;
+                // eight pairs, every stage over all of them: independent chains side by side
+                f32x2v x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    x[k] = f32x2v{av[2 * k], av[2 * k + 1]} + f32x2v{bv[k >> 1][(2 * k) & 3], bv[k >> 1][((2 * k) & 3) + 1]};
+                if constexpr (GELU) {
+                    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
+                    f32x2v t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = x[k] * x[k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = __builtin_elementwise_fma(t[k], f32x2v{k2, k2}, f32x2v{k1, k1});
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = x[k] * t[k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = f32x2v{__builtin_amdgcn_exp2f(t[k].x), __builtin_amdgcn_exp2f(t[k].y)};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = t[k] + f32x2v{1.0f, 1.0f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = f32x2v{__builtin_amdgcn_rcpf(t[k].x), __builtin_amdgcn_rcpf(t[k].y)};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[k] = x[k] * t[k];
+                }
+                if constexpr (OUT_BF16) {
+                    unsigned pk[8];  // pk[2 g + e]: columns 8 g + 4 hh + {2 e, 2 e + 1}
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pk[k] = cvt_pk_bf16(x[k].x, x[k].y);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        // lanes 32-63 of the run g = 2p swap with lanes 0-31 of the run g = 2p + 1: afterwards the lower
+                        // half-wave holds columns 16p .. 16p + 7 and the upper one 16p + 8 .. 16p + 15
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * p + 0], pk[4 * p + 2], false, false);
+                        const auto s1_ = __builtin_amdgcn_permlane32_swap(pk[4 * p + 1], pk[4 * p + 3], false, false);
+                        const u32x4 o = {s0[0], s1_[0], s0[1], s1_[1]};
+                        const int col = gcol + 16 * p + 8 * hhe;
+                        const unsigned off = (col < N ? row_off + (unsigned)col * 2u : 0xFFFFFFFFu) | no_store;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rc, off, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = gcol + 8 * g + 4 * hhe;
+                        const unsigned off = (col < N ? row_off + (unsigned)col * 4u : 0xFFFFFFFFu) | no_store;
+                        const f32x4v o = {x[2 * g].x, x[2 * g].y, x[2 * g + 1].x, x[2 * g + 1].y};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, 0);
+                    }
+                }
+            }
+        }
+        ZG_SB();
+    };
+    auto next_tile = [&]() {
+        idx = nidx;
+        m0 = ntm * 256;
+        n0 = ntn * P::BN;
+        curA = nxtA;
+        curB = nxtB;
+        nidx = idx + gx;
+        nxtA = kOob;
+        nxtB = kOob;
+        if (nidx < t_end) {
+            tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
+            nxtA = (unsigned)ntm * strideA;
+            nxtB = (unsigned)ntn * strideB;
+        }
+    };
+    auto advance = [&]() {  // K-step t -> t + 1; true at the end of the tile
+        if (++kk_cur == kpp) {
+            kk_cur = 0;
+            ++pi_cur;
+        }
+        if (pi_cur < pl.npairs) return false;
+        pi_cur = 0;
+        return true;
+    };
+
+    // ---- prologue: the stream in steady-state order up to the start of K-step 0 — B, A half 0 of K-step 0 (the A half 1
+    // of "K-step -1" is skipped), then B, A half 1 of K-step 0 ... wait: per K-step the stream carries
+    // [B of t + 2, A half 1 of t + 1, A half 0 of t + 2]; before K-step 0 that is [B 0, A0 0] and [B 1, A1 0, A0 1].
+    {
+        const Ahead s0 = ahead(0);
+        s1 = ahead(1);
+        s2 = s1;
+#pragma unroll
+        for (int i = 0; i < P::PB; ++i) dma_b(0, i, s0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(0, 0, i, s0);
+#pragma unroll
+        for (int i = 0; i < P::PB; ++i) dma_b(1, i, s1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(0, 1, i, s0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(1, 0, i, s1);
+        if constexpr (P::PB == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // B and A half 0 of K-step 0 are in
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        bar();
+        read_kstep_head(Ic<0>{});
+    }
+
+    // two K-steps per trip so that the slot is a compile-time constant; a tile may end after either
+    for (;;) {
+        kstep(Ic<0>{});
+        if (advance()) {
+            settle(Ic<1>{});
+            epilogue();
+            if (idx + gx >= t_end) break;
+            next_tile();
+        }
+        kstep(Ic<1>{});
+        if (advance()) {
+            settle(Ic<0>{});
+            epilogue();
+            if (idx + gx >= t_end) break;
+            next_tile();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // zero-fill pieces of "no next tile" still write this workgroup's LDS
+    if (stamp && lane == 0) {
+        g_s4_stamps[0] = gridDim.x;
+        g_s4_stamps[1 + 2 * bid] = t_start;
+        g_s4_stamps[2 + 2 * bid] = __builtin_readcyclecounter();
+    }
+}
+
+template <int NT, bool GELU, bool OUT_BF16, int ABL>
+int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, hipStream_t s) {
+    using P = S4<NT>;
+    static bool raised = false;
+    if (!raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, GELU, OUT_BF16, ABL>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
+        raised = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + P::BN - 1) / P::BN, n_tiles = tiles_m * tiles_n;
+    const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
+    int gw = gw_env > 0 ? gw_env : 8;
+    if (gw > tiles_n) gw = tiles_n;
+    const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;  // tests: few workgroups, many tiles each
+    const int cus = cus_env > 0 ? cus_env : 256;
+    const int grid = n_tiles < cus ? n_tiles : cus;
+    hipLaunchKernelGGL((gemm_s4_kernel<NT, GELU, OUT_BF16, ABL>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N, pl, ldc,
+                       tiles_m, tiles_n, gw, getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+template <int NT, bool GELU, bool OUT_BF16>
+int launch_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, hipStream_t s) {
+    if constexpr (NT == 3 && GELU && OUT_BF16) {  // the benchmarked instantiation carries the ablation builds
+        const int abl = getenv("ZGPT2_S4_ABL") ? atoi(getenv("ZGPT2_S4_ABL")) : 0;
+        switch (abl) {
+            case 1: return launch_s4_abl<NT, GELU, OUT_BF16, 1>(A, B, bias, C, M, N, pl, ldc, s);
+            case 2: return launch_s4_abl<NT, GELU, OUT_BF16, 2>(A, B, bias, C, M, N, pl, ldc, s);
+            case 3: return launch_s4_abl<NT, GELU, OUT_BF16, 3>(A, B, bias, C, M, N, pl, ldc, s);
+            case 4: return launch_s4_abl<NT, GELU, OUT_BF16, 4>(A, B, bias, C, M, N, pl, ldc, s);
+            case 7: return launch_s4_abl<NT, GELU, OUT_BF16, 7>(A, B, bias, C, M, N, pl, ldc, s);
+            case 8: return launch_s4_abl<NT, GELU, OUT_BF16, 8>(A, B, bias, C, M, N, pl, ldc, s);
+            case 9: return launch_s4_abl<NT, GELU, OUT_BF16, 9>(A, B, bias, C, M, N, pl, ldc, s);
+            case 11: return launch_s4_abl<NT, GELU, OUT_BF16, 11>(A, B, bias, C, M, N, pl, ldc, s);
+            default: break;
+        }
+    }
+    return launch_s4_abl<NT, GELU, OUT_BF16, 0>(A, B, bias, C, M, N, pl, ldc, s);
+}
+
+template <int NT>
+int launch_s4_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
+                 bool gelu, bool out_bf16, hipStream_t s) {
+    if (gelu) return out_bf16 ? launch_s4<NT, true, true>(A, B, bias, C, M, N, pl, ldc, s)
+                              : launch_s4<NT, true, false>(A, B, bias, C, M, N, pl, ldc, s);
+    return out_bf16 ? launch_s4<NT, false, true>(A, B, bias, C, M, N, pl, ldc, s)
+                    : launch_s4<NT, false, false>(A, B, bias, C, M, N, pl, ldc, s);
+}
+
+}  // namespace
+
+int gemm_s4_stamps(unsigned long long* out, size_t n_words) {
+    if (n_words > 1 + 2 * 256 + 16) n_words = 1 + 2 * 256 + 16;
+    ZG_HIP(hipDeviceSynchronize());
+    ZG_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s4_stamps), n_words * sizeof(unsigned long long)));
+    return ZG_OK;
+}
+
+int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
+                   bool gelu, bool out_bf16, int bn, hipStream_t s) {
+    return bn == 192 ? launch_s4_nt<3>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
+                     : launch_s4_nt<4>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
+}
+
+}  // namespace zg

@@ -132,6 +132,9 @@ struct GemmPlanes {
 };
 int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl,
                        int ldc, bool gelu, bool out_bf16, hipStream_t s);
+int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
+                   bool gelu, bool out_bf16, int bn, hipStream_t s);  // gemm_s4.hip
+int gemm_s4_stamps(unsigned long long* out, size_t n_words);  // diagnostic (ZGPT2_GEMM_DBG bit 256)
 unsigned long long gemm_mfma_launch_count();  // launches of the MFMA GEMM so far (tests assert the path taken)
 
 // ------------------------------------------------------------------------------------ prefill (prefill.hip)
