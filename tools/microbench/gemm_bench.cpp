@@ -66,6 +66,7 @@ int main(int argc, char** argv) {
     };
     if (check) {
         CK(hipMemset(dC, 0xFF, (size_t)M * N * esz));
+        CK(hipDeviceSynchronize());  // the library launches on its own non-blocking stream: the memset must be done first
         run();
         std::vector<uint8_t> h0, h1;
         fetch(h0);

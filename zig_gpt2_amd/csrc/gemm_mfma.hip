@@ -557,8 +557,12 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     int bn = cost(192) < cost(256) ? 192 : 256;
     if (bn_env == 192 || bn_env == 256) bn = bn_env;
     ++g_gemm_launches;
-    if (const char* kk = getenv("ZGPT2_GEMM_KERNEL"); kk && !strcmp(kk, "s4"))
-        return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, bn, s);
+    // Two generations of the kernel: the four-wave software-pipelined one (gemm_s4.hip) wherever 192-wide tiles are the
+    // choice (its 256-wide instantiation does not fit the register file without spills yet), the eight-wave one below
+    // for 256-wide tiles.  ZGPT2_GEMM_KERNEL=p8 / s4 forces one (s4 then always with 192-wide tiles).
+    const char* kk = getenv("ZGPT2_GEMM_KERNEL");
+    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8");
+    if (force_s4 || (!force_p8 && bn == 192)) return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, 192, s);
     return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
                      : launch_p8_bn<256>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
 }

@@ -57,7 +57,8 @@ struct S4 {
     static constexpr int BM = 256, BN = 64 * NT;
     static constexpr int A_SLOT = 256 * 128, B_SLOT = BN * 128;
     static constexpr int A_OFF = 0, B_OFF = 2 * A_SLOT;  // [A slot 0][A slot 1][B slot 0][B slot 1]
-    static constexpr int LDS = 2 * A_SLOT + 2 * B_SLOT;  // 112 / 128 KiB
+    static constexpr int BIAS_OFF = 2 * A_SLOT + 2 * B_SLOT;  // two tiles' bias rows (fp32), by tile parity
+    static constexpr int LDS = BIAS_OFF + 2 * 1024;       // 114 / 130 KiB
     static constexpr int PB = BN / 32;          // B pieces (8 rows x 128 B) per wave per K-step: 6 or 8
     static constexpr int W3 = 8 + PB;           // pieces that may still be in flight when A half 1 of this K-step must have landed
 };
@@ -139,6 +140,21 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * pl.lda * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb =
         __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * pl.ldb * 2), 0x00020000);
+    // The tile's bias row travels through LDS (wave 0 fetches it by LDS-DMA at the start of the tile; columns past N and a
+    // null bias read as zero): the epilogue must not issue a global load — the compiler would wait for it with vmcnt(0),
+    // i.e. drain the stores and the next tile's DMA — and 48 registers of bias held across the epilogue make the register
+    // allocator shuffle accumulators inside the K loop.
+    const __amdgpu_buffer_rsrc_t rbias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, bias != nullptr ? (unsigned)N * 4u : 0u, 0x00020000);
+    int tile_par = 0;
+    auto fetch_bias = [&](int n0_, int par) {
+        if (wave == 0) {
+#pragma unroll
+            for (int p = 0; p < P::BN / 64; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, to_lds(lds_base + P::BIAS_OFF + par * 1024 + p * 256), 4, (unsigned)lane * 4u,
+                                                         (unsigned)(n0_ + 64 * p) * 4u, 0, 0);
+        }
+    };
     const unsigned lda2 = (unsigned)pl.lda * 2u, ldb2 = (unsigned)pl.ldb * 2u;
     const int csrc = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
     const unsigned relA = (unsigned)(wave * 8 + (lane >> 3)) * lda2 + (unsigned)csrc * 16u;
@@ -225,19 +241,52 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ZG_SB();
     };
-    // End of a tile: the fragments of the next tile's first K-step (slot X) are in flight.  Registers written by a hand-issued
-    // ds_read must not be moved by the compiler before the data has landed, and the epilogue's register pressure makes it
-    // move things: wait for them here and hand them back to the compiler as NEW values (the empty statements), so that
-    // whatever it does with them happens behind the wait.
-    auto settle = [&](auto XT) {
-        constexpr int X = decltype(XT)::value;
+    // End of a tile: the fragment reads of steps 3-7 of its last K-step (the next tile's first fragments) are in flight.
+    // Their registers must not be live across the epilogue — its register pressure would make the compiler move them,
+    // possibly before the data has landed, and 112 live fragment registers on top of the epilogue's own make it spill.
+    // So: wait until they have all landed (in registers nobody reads), run the epilogue, and read the next K-step's
+    // fragments again afterwards (read_kstep_head: ~14 reads and one exposed LDS latency per tile).
+    auto settle = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[X][ks][j]));
-        asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]));
         ZG_SB();
+    };
+
+    // ---- deferred stores (bf16 output).  All 256 CUs reach their epilogue together, and 98 KB per CU in one burst is
+    // bounded by the chip's write bandwidth (~4 us per tile), with the next tile's DMA queued behind it in the same memory
+    // pipeline.  So only the first half of a tile's stores leaves from the epilogue (hidden under its arithmetic); the
+    // second half waits in registers and leaves one store per K-step of the NEXT tile, behind barrier 1 (no hand-issued
+    // LDS read is in flight there).  Whatever is still pending at the next epilogue, or at the end, is flushed.
+    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    // MEASURED AND SWITCHED OFF (NPEND = 0): a store issued inside the K loop sits among the DMA pieces on the wave's vmcnt
+    // counter, completes late under the chip-wide write burst, and every counted wait behind it stalls (50.4 against 45.2 us).
+    constexpr int NPEND = 0;  // OUT_BF16 ? 4 * NT : 0
+    u32x4 pend[NPEND > 0 ? NPEND : 1];
+    unsigned pend_row = 0, no_store_mask = (dbg & 1) ? 0xFFFFFFFFu : 0u;  // byte offset of (row l31 of m-tile 0, wave's column 0)
+    int pend_col = 0, pend_n = NPEND;                                       // wave's first column + 8 hh; stores issued so far
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)((size_t)M * ldc * ESZ), 0x00020000);
+    auto store_q = [&](auto QT, const u32x4& o, unsigned row0, int col0) {  // store q = (j * 4 + i) * 2 + p of a tile
+        constexpr int q = decltype(QT)::value, i = (q / 2) % 4, j = (q / 2) / 4, pp = q % 2;
+        const int col = col0 + j * 32 + 16 * pp;
+        const unsigned off = (col < N ? row0 + (unsigned)(i * 32) * (unsigned)(ldc * ESZ) + (unsigned)(col * ESZ) : 0xFFFFFFFFu) | no_store_mask;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rc, off, 0, 0);
+    };
+    auto emit_pending = [&](int k) {  // pending store k (uniform)
+        if constexpr (NPEND > 0) {
+            switch (k) {
+#define ZG_PEND_CASE(K) \
+    case K: \
+        if constexpr (K < NPEND) store_q(Ic<NPEND + (K < NPEND ? K : 0)>{}, pend[K < NPEND ? K : 0], pend_row, pend_col); \
+        break;
+                ZG_PEND_CASE(0) ZG_PEND_CASE(1) ZG_PEND_CASE(2) ZG_PEND_CASE(3) ZG_PEND_CASE(4) ZG_PEND_CASE(5) ZG_PEND_CASE(6) ZG_PEND_CASE(7)
+                ZG_PEND_CASE(8) ZG_PEND_CASE(9) ZG_PEND_CASE(10) ZG_PEND_CASE(11) ZG_PEND_CASE(12) ZG_PEND_CASE(13) ZG_PEND_CASE(14) ZG_PEND_CASE(15)
+#undef ZG_PEND_CASE
+                default: break;
+            }
+        }
+    };
+    auto flush_pending = [&]() {
+        if constexpr (NPEND > 0)
+            for (; pend_n < NPEND; ++pend_n) emit_pending(pend_n);
     };
 
     Ahead s1, s2;  // stream positions t + 1 / t + 2 of the current K-step t
@@ -266,6 +315,13 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             if constexpr (P::PB == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             bar();
+            if constexpr (NPEND > 0) {
+                if (pend_n < NPEND) {
+                    emit_pending(pend_n);
+                    ++pend_n;
+                }
+                ZG_SB();
+            }
         }
         if constexpr (J == 7) {  // barrier 2: A half 1 of this slot and B of the other are read out (step 6 issued the last reads)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -339,7 +395,6 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // ---- epilogue of one tile, straight from the registers: lane (l31, hh) holds output row l31 of each 32 x 32
     // tile and columns 8 g + 4 hh + {0..3} (register 4 g + e).  bf16: v_permlane32_swap makes 8 consecutive
     // columns (16 B) per lane out of the two half-waves' runs of 4.
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
     auto epilogue = [&]() {
         if (dbg & 4) {  // diagnostic: no epilogue at all
             float tsum = 0.0f;
@@ -360,27 +415,20 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         const int l31e = lane_e & 31, hhe = lane_e >> 5;
         // Stores go through a buffer descriptor: a row past M lies past the descriptor's end and a column past N gets an
         // out-of-range offset, so the hardware drops them — no exec masking, one straight block of code per tile.
-        const __amdgpu_buffer_rsrc_t rc =
-            __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)((size_t)M * ldc * ESZ), 0x00020000);
+        flush_pending();  // (a tile of fewer K-steps than pending stores)
         const f32x16v zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        const unsigned no_store = (dbg & 1) ? 0xFFFFFFFFu : 0u;
-        // every bias value of the tile first: a load behind a store would make the compiler drain the stores (vmcnt(0))
-        f32x4v bva[NT][4];
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int col = n0 + wc * (P::BN / 2) + j * 32 + 8 * g + 4 * hhe;
-                col = min(col, N - 4);  // columns past N are dropped at the store; keep the address valid
-                bva[j][g] = bias != nullptr ? *reinterpret_cast<const f32x4v*>(bias + col) : f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
-            }
+        const unsigned row0 = (unsigned)(m0 + wr * 128 + l31e) * (unsigned)(ldc * ESZ);
+        const int col0 = n0 + wc * (P::BN / 2) + 8 * hhe;
+        const unsigned bias_addr = lds_base + P::BIAS_OFF + tile_par * 1024 + (unsigned)(wc * (P::BN / 2) + 4 * hhe) * 4u;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int gcol = n0 + wc * (P::BN / 2) + j * 32;
-            const f32x4v(&bv)[4] = bva[j];
+            f32x4v bv[4];  // columns gcol + 8 g + 4 hh + {0..3}
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[g]) : "v"(bias_addr), "i"((j * 32 + 8 * g) * 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const unsigned row_off = (unsigned)(m0 + wr * 128 + i * 32 + l31e) * (unsigned)(ldc * ESZ);
                 const f32x16v av = acc[i][j];
                 acc[i][j] = zero16;
                 // eight pairs, every stage over all of them: independent chains side by side
@@ -417,20 +465,29 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * p + 0], pk[4 * p + 2], false, false);
                         const auto s1_ = __builtin_amdgcn_permlane32_swap(pk[4 * p + 1], pk[4 * p + 3], false, false);
                         const u32x4 o = {s0[0], s1_[0], s0[1], s1_[1]};
-                        const int col = gcol + 16 * p + 8 * hhe;
-                        const unsigned off = (col < N ? row_off + (unsigned)col * 2u : 0xFFFFFFFFu) | no_store;
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rc, off, 0, 0);
+                        const int q = (j * 4 + i) * 2 + p;  // a constant once the loops are unrolled
+                        if (NPEND == 0 || q < NPEND) {      // (first half of the tile:) out now
+                            const int col = col0 + j * 32 + 16 * p;
+                            const unsigned off = (col < N ? row0 + (unsigned)(i * 32) * (unsigned)(ldc * 2) + (unsigned)col * 2u : 0xFFFFFFFFu) | no_store_mask;
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rc, off, 0, 0);
+                        } else
+                            pend[q - NPEND] = o;            // second half: one store per K-step of the next tile
                     }
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int col = gcol + 8 * g + 4 * hhe;
-                        const unsigned off = (col < N ? row_off + (unsigned)col * 4u : 0xFFFFFFFFu) | no_store;
+                        const unsigned off = (col < N ? row0 + (unsigned)(i * 32) * (unsigned)(ldc * 4) + (unsigned)col * 4u : 0xFFFFFFFFu) | no_store_mask;
                         const f32x4v o = {x[2 * g].x, x[2 * g].y, x[2 * g + 1].x, x[2 * g + 1].y};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, 0);
                     }
                 }
             }
+        }
+        if constexpr (NPEND > 0) {
+            pend_row = row0;
+            pend_col = col0;
+            pend_n = 0;
         }
         ZG_SB();
     };
@@ -438,6 +495,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         idx = nidx;
         m0 = ntm * 256;
         n0 = ntn * P::BN;
+        tile_par ^= 1;
+        fetch_bias(n0, tile_par);
         curA = nxtA;
         curB = nxtB;
         nidx = idx + gx;
@@ -463,6 +522,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // of "K-step -1" is skipped), then B, A half 1 of K-step 0 ... wait: per K-step the stream carries
     // [B of t + 2, A half 1 of t + 1, A half 0 of t + 2]; before K-step 0 that is [B 0, A0 0] and [B 1, A1 0, A0 1].
     {
+        fetch_bias(n0, 0);
         const Ahead s0 = ahead(0);
         s1 = ahead(1);
         s2 = s1;
@@ -486,19 +546,22 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     for (;;) {
         kstep(Ic<0>{});
         if (advance()) {
-            settle(Ic<1>{});
+            settle();
             epilogue();
             if (idx + gx >= t_end) break;
             next_tile();
+            read_kstep_head(Ic<1>{});
         }
         kstep(Ic<1>{});
         if (advance()) {
-            settle(Ic<0>{});
+            settle();
             epilogue();
             if (idx + gx >= t_end) break;
             next_tile();
+            read_kstep_head(Ic<0>{});
         }
     }
+    flush_pending();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // zero-fill pieces of "no next tile" still write this workgroup's LDS
     if (stamp && lane == 0) {
         g_s4_stamps[0] = gridDim.x;
