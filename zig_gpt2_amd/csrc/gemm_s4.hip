@@ -58,7 +58,9 @@ struct S4 {
     static constexpr int A_SLOT = 256 * 128, B_SLOT = BN * 128;
     static constexpr int A_OFF = 0, B_OFF = 2 * A_SLOT;  // [A slot 0][A slot 1][B slot 0][B slot 1]
     static constexpr int BIAS_OFF = 2 * A_SLOT + 2 * B_SLOT;  // two tiles' bias rows (fp32), by tile parity
-    static constexpr int LDS = BIAS_OFF + 2 * 1024;       // 114 / 130 KiB
+    // bf16 epilogue staging, per wave: one 32-row m-tile x the wave's BN / 2 columns, rows padded by 16 B
+    static constexpr int ST_ROW = NT * 64 + 16, ST_WAVE = 32 * ST_ROW, ST_OFF = BIAS_OFF + 2 * 1024;
+    static constexpr int LDS = ST_OFF + 4 * ST_WAVE;      // 140 / 164 KiB
     static constexpr int PB = BN / 32;          // B pieces (8 rows x 128 B) per wave per K-step: 6 or 8
     static constexpr int W3 = 8 + PB;           // pieces that may still be in flight when A half 1 of this K-step must have landed
 };
@@ -81,6 +83,14 @@ __device__ __forceinline__ void tile_of(int idx, int tiles_m, int tiles_n, int g
 
 template <int I>
 using Ic = std::integral_constant<int, I>;
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(Ic<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 struct Ahead {  // where a K-step of the DMA stream comes from
     unsigned baseA, baseB, kbA, kbB;
@@ -97,6 +107,32 @@ template <int NT, int X, int J, int I>
 __device__ __forceinline__ void read_frag_b(bf16x8& f, const unsigned (&b_addr)[4]) {
     using P = S4<NT>;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(b_addr[J & 3]), "i"(X * P::B_SLOT + I * 4096));
+}
+
+// ---- The accumulators are OWNED BY HAND: tile (i, j) of a wave lives in a[16 (i NT + j) : +15], written only by the inline-asm
+// MFMAs below and read / zeroed only by the inline-asm moves of the epilogue.  Left to the register allocator, a change in
+// the epilogue's register pressure made it park accumulators in VGPRs and shuffle them with v_accvgpr_mov inside the K loop
+// (dependent on the MFMAs: +14k cycles per launch).  Every statement that touches them names all of them as clobbered, so
+// the compiler keeps nothing of its own there across any of them; what remains to audit after an edit is that no
+// compiler-generated v_accvgpr_* names a0..a191 (tools/README: grep recipe).  Hazards are ours too: MFMA result ->
+// v_accvgpr_read needs the pipeline drained (s_nop in acc_settle), v_accvgpr_write -> MFMA source C two wait states.
+#define ZG_ACC_CLOBBERS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
+template <int BASE>
+__device__ __forceinline__ void mfma_acc(const bf16x8& a_op, const bf16x8& b_op) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a_op), "v"(b_op), "i"(BASE), "i"(BASE + 15) : ZG_ACC_CLOBBERS);
+}
+template <int REG>
+__device__ __forceinline__ float acc_take(void) {  // read one accumulator register and zero it
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]\n\tv_accvgpr_write_b32 a[%c1], 0" : "=v"(v) : "i"(REG) : ZG_ACC_CLOBBERS);
+    return v;
+}
+template <int REG>
+__device__ __forceinline__ void acc_zero(void) {
+    asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(REG) : ZG_ACC_CLOBBERS);
+}
+__device__ __forceinline__ void acc_settle(void) {  // after the last MFMA, before the first read: the 8-pass pipeline drains
+    asm volatile("s_nop 15\n\ts_nop 15" ::: ZG_ACC_CLOBBERS);
 }
 
 template <int NT, int X>
@@ -215,13 +251,10 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         const unsigned dst = lds_base + P::B_OFF + X * P::B_SLOT + (wave + 4 * i) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, to_lds(dst), 16, relB, s.baseB + (unsigned)(i * 32) * ldb2 + s.kbB, 0, 0);
     };
-    f32x16v acc[4][NT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // accumulators: a[0 : 16 * 4 * NT - 1], owned by hand (see mfma_acc); start at zero
+    static_assert(NT == 3, "the hand-owned accumulator file is laid out for NT = 3 (192 registers)");
+    static_for<16 * 4 * NT>([&](auto RT) { acc_zero<decltype(RT)::value>(); });
+    asm volatile("s_nop 4" ::: ZG_ACC_CLOBBERS);
     // Fragments.  A: two buffers by step parity (2 tiles of 32 rows, one k-slice).  B: the WHOLE K-step of this wave's
     // columns (4 k-slices x NT tiles), two buffers by K-step parity — B is read from LDS once per K-step (both
     // phases multiply the same B fragments), during steps 3..6 of the K-step before.
@@ -366,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                 if constexpr (m == NT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(mine) : "memory");
                 if constexpr (m == 0 || m == NT) ZG_SB();
             }
-            acc[h * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[X][ks][j], fa[cb][i], acc[h * 2 + i][j], 0, 0, 0);
+            mfma_acc<16 * ((h * 2 + i) * NT + j)>(fb[X][ks][j], fa[cb][i]);
             gap(MT);
         };
         mma(Ic<0>{});
@@ -396,18 +429,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // tile and columns 8 g + 4 hh + {0..3} (register 4 g + e).  bf16: v_permlane32_swap makes 8 consecutive
     // columns (16 B) per lane out of the two half-waves' runs of 4.
     auto epilogue = [&]() {
-        if (dbg & 4) {  // diagnostic: no epilogue at all
-            float tsum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        tsum += acc[i][j][r];
-                        acc[i][j][r] = 0.0f;
-                    }
-            if (tsum == 1.2345e33f) reinterpret_cast<float*>(C)[0] = tsum;
+        acc_settle();
+        if (dbg & 4) {  // diagnostic: no epilogue at all (the accumulators just keep running)
             return;
         }
         int lane_e = lane;  // opaque copy: nothing derived from it can be hoisted into (and kept across) the main loop
@@ -416,21 +439,46 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         // Stores go through a buffer descriptor: a row past M lies past the descriptor's end and a column past N gets an
         // out-of-range offset, so the hardware drops them — no exec masking, one straight block of code per tile.
         flush_pending();  // (a tile of fewer K-steps than pending stores)
-        const f32x16v zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         const unsigned row0 = (unsigned)(m0 + wr * 128 + l31e) * (unsigned)(ldc * ESZ);
         const int col0 = n0 + wc * (P::BN / 2) + 8 * hhe;
+        // the tile's bias row (LDS): columns wc BN/2 + 32 j + 8 g + 4 hh + {0..3}
         const unsigned bias_addr = lds_base + P::BIAS_OFF + tile_par * 1024 + (unsigned)(wc * (P::BN / 2) + 4 * hhe) * 4u;
+        f32x4v bva[NT][4];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int gcol = n0 + wc * (P::BN / 2) + j * 32;
-            f32x4v bv[4];  // columns gcol + 8 g + 4 hh + {0..3}
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[g]) : "v"(bias_addr), "i"((j * 32 + 8 * g) * 4));
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+            for (int g = 0; g < 4; ++g)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bva[j][g]) : "v"(bias_addr), "i"((j * 32 + 8 * g) * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x16v av = acc[i][j];
-                acc[i][j] = zero16;
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bva[j][0]), "+v"(bva[j][1]), "+v"(bva[j][2]), "+v"(bva[j][3]));
+        // bf16: a lane's runs of 4 columns go through a wave-private LDS image of the m-tile and leave as 16-B pieces of
+        // whole rows (a store instruction that scatters 32-B pieces over 32 rows costs one L2 request per piece: the
+        // epilogue was bounded by the request rate of the L2s, 6.8k cycles per tile)
+        constexpr int CPR = NT * 4, NCH = 2 * NT;   // 16-B chunks per staged row; chunks (= stores) per lane per m-tile
+        const unsigned st_w = lds_base + P::ST_OFF + wave * P::ST_WAVE + (unsigned)l31e * P::ST_ROW + (unsigned)hhe * 8u;
+        unsigned st_r[NCH], g_off[NCH];
+        if constexpr (OUT_BF16) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int c = lane_e + 64 * k, row = c / CPR, ch = c % CPR;
+                st_r[k] = lds_base + P::ST_OFF + wave * P::ST_WAVE + (unsigned)row * P::ST_ROW + (unsigned)ch * 16u;
+                const int col = n0 + wc * (P::BN / 2) + ch * 8;
+                g_off[k] = (col < N ? (unsigned)(m0 + wr * 128 + row) * (unsigned)(ldc * 2) + (unsigned)col * 2u : 0xFFFFFFFFu) | no_store_mask;
+            }
+        }
+        static_for<4>([&](auto IT) {
+            constexpr int i = decltype(IT)::value;
+            static_for<NT>([&](auto JT) {
+                constexpr int j = decltype(JT)::value;
+                const int gcol = n0 + wc * (P::BN / 2) + j * 32;
+                const f32x4v(&bv)[4] = bva[j];
+                // (a 16-byte store reads its data registers a little after it issues; the compiler pads that hazard for its own
+                // instructions only, and the moves below are ours: without the pad they overwrote the previous m-tile's store
+                // data now and then)
+                asm volatile("s_nop 3" ::: "memory");
+                float av[16];
+                static_for<16>([&](auto RT) { av[decltype(RT)::value] = acc_take<16 * (i * NT + j) + decltype(RT)::value>(); });
                 // eight pairs, every stage over all of them: independent chains side by side
                 f32x2v x[8];
 #pragma unroll
@@ -455,23 +503,11 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                     for (int k = 0; k < 8; ++k) x[k] = x[k] * t[k];
                 }
                 if constexpr (OUT_BF16) {
-                    unsigned pk[8];  // pk[2 g + e]: columns 8 g + 4 hh + {2 e, 2 e + 1}
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) pk[k] = cvt_pk_bf16(x[k].x, x[k].y);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        // lanes 32-63 of the run g = 2p swap with lanes 0-31 of the run g = 2p + 1: afterwards the lower
-                        // half-wave holds columns 16p .. 16p + 7 and the upper one 16p + 8 .. 16p + 15
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * p + 0], pk[4 * p + 2], false, false);
-                        const auto s1_ = __builtin_amdgcn_permlane32_swap(pk[4 * p + 1], pk[4 * p + 3], false, false);
-                        const u32x4 o = {s0[0], s1_[0], s0[1], s1_[1]};
-                        const int q = (j * 4 + i) * 2 + p;  // a constant once the loops are unrolled
-                        if (NPEND == 0 || q < NPEND) {      // (first half of the tile:) out now
-                            const int col = col0 + j * 32 + 16 * p;
-                            const unsigned off = (col < N ? row0 + (unsigned)(i * 32) * (unsigned)(ldc * 2) + (unsigned)col * 2u : 0xFFFFFFFFu) | no_store_mask;
-                            __builtin_amdgcn_raw_buffer_store_b128(o, rc, off, 0, 0);
-                        } else
-                            pend[q - NPEND] = o;            // second half: one store per K-step of the next tile
+                    for (int g = 0; g < 4; ++g) {  // columns 32 j + 8 g + 4 hh + {0..3} of row l31: 8 bytes
+                        const u32x2 pk = {cvt_pk_bf16(x[2 * g].x, x[2 * g].y), cvt_pk_bf16(x[2 * g + 1].x, x[2 * g + 1].y)};
+                        const unsigned st_w_l = st_w;  // (a generic lambda does not capture what only an asm operand names)
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(st_w_l), "v"(pk), "i"(j * 64 + g * 16) : "memory");
                     }
                 } else {
 #pragma unroll
@@ -482,8 +518,26 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, 0);
                     }
                 }
+            });
+            if constexpr (OUT_BF16) {  // the m-tile back out as rows (LDS serves a wave's accesses in order: no wait between write and read)
+                u32x4 o[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const unsigned st_r_l = st_r[k];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(o[k]) : "v"(st_r_l) : "memory");
+                }
+                if constexpr (NCH == 6)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]));
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const unsigned off = g_off[k] == 0xFFFFFFFFu ? g_off[k] : g_off[k] + (unsigned)(i * 32) * (unsigned)(ldc * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(o[k], rc, off, 0, 0);
+                }
             }
-        }
+        });
+        asm volatile("s_nop 4" ::: ZG_ACC_CLOBBERS);  // the zeroing v_accvgpr_writes -> the next tile's first MFMAs
         if constexpr (NPEND > 0) {
             pend_row = row0;
             pend_col = col0;
@@ -551,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             if (idx + gx >= t_end) break;
             next_tile();
             read_kstep_head(Ic<1>{});
+            bar();  // every wave has re-read the new tile's first B fragments: steps 0-2 may now overwrite that B region
         }
         kstep(Ic<1>{});
         if (advance()) {
@@ -559,6 +614,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             if (idx + gx >= t_end) break;
             next_tile();
             read_kstep_head(Ic<0>{});
+            bar();
         }
     }
     flush_pending();
@@ -631,8 +687,8 @@ int gemm_s4_stamps(unsigned long long* out, size_t n_words) {
 
 int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
                    bool gelu, bool out_bf16, int bn, hipStream_t s) {
-    return bn == 192 ? launch_s4_nt<3>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
-                     : launch_s4_nt<4>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
+    (void)bn;  // 192-wide tiles only: 256 x 256 needs all 256 accumulator registers plus 128 of B fragments
+    return launch_s4_nt<3>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
 }
 
 }  // namespace zg
