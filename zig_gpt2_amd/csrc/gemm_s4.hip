@@ -121,11 +121,44 @@ template <int BASE>
 __device__ __forceinline__ void mfma_acc(const bf16x8& a_op, const bf16x8& b_op) {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a_op), "v"(b_op), "i"(BASE), "i"(BASE + 15) : ZG_ACC_CLOBBERS);
 }
-template <int REG>
-__device__ __forceinline__ float acc_take(void) {  // read one accumulator register and zero it
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c1]\n\tv_accvgpr_write_b32 a[%c1], 0" : "=v"(v) : "i"(REG) : ZG_ACC_CLOBBERS);
-    return v;
+template <int BASE>
+__device__ __forceinline__ void acc_read8(float* v) {  // eight accumulator registers, one statement
+    asm volatile(
+        "v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\tv_accvgpr_read_b32 %3, a[%c11]\n\t"
+        "v_accvgpr_read_b32 %4, a[%c12]\n\tv_accvgpr_read_b32 %5, a[%c13]\n\tv_accvgpr_read_b32 %6, a[%c14]\n\tv_accvgpr_read_b32 %7, a[%c15]"
+        : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7])
+        : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3), "i"(BASE + 4), "i"(BASE + 5), "i"(BASE + 6), "i"(BASE + 7)
+        : ZG_ACC_CLOBBERS);
+}
+template <int BASE>
+__device__ __forceinline__ void acc_read16(float (&v)[16]) {  // the 16 registers of one 32 x 32 tile
+    acc_read8<BASE>(v);
+    acc_read8<BASE + 8>(v + 8);
+}
+// A tile starts at its bias (the reference pre-fills the output with the bias, src/ops.zig:24-29).  The four 32 x 32 tiles of
+// one column tile j share the bias pattern of their 16 registers: it goes into the scratch accumulator a[192:207] once and
+// four MFMAs of zero operands copy it (0 x 0 + C; destination and C of an MFMA must both be accumulator registers) — on
+// the idle matrix pipe, instead of 64 v_accvgpr_writes now and 32 packed adds in the epilogue.  One statement, so that the
+// compiler can hold nothing in a[192:207] across it.
+template <int B0, int B1, int B2, int B3>
+__device__ __forceinline__ void acc_init4(const bf16x8& zero_op, const f32x4v& g0, const f32x4v& g1, const f32x4v& g2, const f32x4v& g3) {
+    asm volatile(
+        "v_accvgpr_write_b32 a192, %1\n\tv_accvgpr_write_b32 a193, %2\n\tv_accvgpr_write_b32 a194, %3\n\tv_accvgpr_write_b32 a195, %4\n\t"
+        "v_accvgpr_write_b32 a196, %5\n\tv_accvgpr_write_b32 a197, %6\n\tv_accvgpr_write_b32 a198, %7\n\tv_accvgpr_write_b32 a199, %8\n\t"
+        "v_accvgpr_write_b32 a200, %9\n\tv_accvgpr_write_b32 a201, %10\n\tv_accvgpr_write_b32 a202, %11\n\tv_accvgpr_write_b32 a203, %12\n\t"
+        "v_accvgpr_write_b32 a204, %13\n\tv_accvgpr_write_b32 a205, %14\n\tv_accvgpr_write_b32 a206, %15\n\tv_accvgpr_write_b32 a207, %16\n\t"
+        "s_nop 3\n\t"
+        "v_mfma_f32_32x32x16_bf16 a[%c17:%c18], %0, %0, a[192:207]\n\t"
+        "v_mfma_f32_32x32x16_bf16 a[%c19:%c20], %0, %0, a[192:207]\n\t"
+        "v_mfma_f32_32x32x16_bf16 a[%c21:%c22], %0, %0, a[192:207]\n\t"
+        "v_mfma_f32_32x32x16_bf16 a[%c23:%c24], %0, %0, a[192:207]\n\t"
+        "s_nop 7"
+        :
+        : "v"(zero_op), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]), "v"(g1[2]), "v"(g1[3]), "v"(g2[0]), "v"(g2[1]),
+          "v"(g2[2]), "v"(g2[3]), "v"(g3[0]), "v"(g3[1]), "v"(g3[2]), "v"(g3[3]), "i"(B0), "i"(B0 + 15), "i"(B1), "i"(B1 + 15), "i"(B2),
+          "i"(B2 + 15), "i"(B3), "i"(B3 + 15)
+        : ZG_ACC_CLOBBERS, "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206",
+          "a207");
 }
 template <int REG>
 __device__ __forceinline__ void acc_zero(void) {
@@ -182,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // allocator shuffle accumulators inside the K loop.
     const __amdgpu_buffer_rsrc_t rbias =
         __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, bias != nullptr ? (unsigned)N * 4u : 0u, 0x00020000);
-    int tile_par = 0;
+    int tile_par = 0;  // parity of the current tile: its bias row is in buffer tile_par, the next tile's in the other one
     auto fetch_bias = [&](int n0_, int par) {
         if (wave == 0) {
 #pragma unroll
@@ -253,8 +286,22 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     };
     // accumulators: a[0 : 16 * 4 * NT - 1], owned by hand (see mfma_acc); start at zero
     static_assert(NT == 3, "the hand-owned accumulator file is laid out for NT = 3 (192 registers)");
-    static_for<16 * 4 * NT>([&](auto RT) { acc_zero<decltype(RT)::value>(); });
-    asm volatile("s_nop 4" ::: ZG_ACC_CLOBBERS);
+    // every tile starts at its bias row (buffer `par` of the LDS bias area): 12 MFMAs, see acc_init
+    auto init_acc_from_bias = [&](int par) {
+        const unsigned baddr = lds_base + P::BIAS_OFF + par * 1024 + (unsigned)(wc * (P::BN / 2) + 4 * (lane >> 5)) * 4u;
+        bf16x8 zop;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zop[e] = (__bf16)0.0f;
+        static_for<NT>([&](auto JT) {
+            constexpr int j = decltype(JT)::value;
+            const unsigned baddr_l = baddr;
+            f32x4v b4[4];  // columns 32 j + 8 g + 4 hh + {0..3}: registers 4 g .. 4 g + 3 of the tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b4[g]) : "v"(baddr_l), "i"((j * 32 + 8 * g) * 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+            acc_init4<16 * (0 * NT + j), 16 * (1 * NT + j), 16 * (2 * NT + j), 16 * (3 * NT + j)>(zop, b4[0], b4[1], b4[2], b4[3]);
+        });
+    };
     // Fragments.  A: two buffers by step parity (2 tiles of 32 rows, one k-slice).  B: the WHOLE K-step of this wave's
     // columns (4 k-slices x NT tiles), two buffers by K-step parity — B is read from LDS once per K-step (both
     // phases multiply the same B fragments), during steps 3..6 of the K-step before.
@@ -441,17 +488,6 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         flush_pending();  // (a tile of fewer K-steps than pending stores)
         const unsigned row0 = (unsigned)(m0 + wr * 128 + l31e) * (unsigned)(ldc * ESZ);
         const int col0 = n0 + wc * (P::BN / 2) + 8 * hhe;
-        // the tile's bias row (LDS): columns wc BN/2 + 32 j + 8 g + 4 hh + {0..3}
-        const unsigned bias_addr = lds_base + P::BIAS_OFF + tile_par * 1024 + (unsigned)(wc * (P::BN / 2) + 4 * hhe) * 4u;
-        f32x4v bva[NT][4];
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bva[j][g]) : "v"(bias_addr), "i"((j * 32 + 8 * g) * 4));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bva[j][0]), "+v"(bva[j][1]), "+v"(bva[j][2]), "+v"(bva[j][3]));
         // bf16: a lane's runs of 4 columns go through a wave-private LDS image of the m-tile and leave as 16-B pieces of
         // whole rows (a store instruction that scatters 32-B pieces over 32 rows costs one L2 request per piece: the
         // epilogue was bounded by the request rate of the L2s, 6.8k cycles per tile)
@@ -472,18 +508,16 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             static_for<NT>([&](auto JT) {
                 constexpr int j = decltype(JT)::value;
                 const int gcol = n0 + wc * (P::BN / 2) + j * 32;
-                const f32x4v(&bv)[4] = bva[j];
                 // (a 16-byte store reads its data registers a little after it issues; the compiler pads that hazard for its own
                 // instructions only, and the moves below are ours: without the pad they overwrote the previous m-tile's store
                 // data now and then)
                 asm volatile("s_nop 3" ::: "memory");
                 float av[16];
-                static_for<16>([&](auto RT) { av[decltype(RT)::value] = acc_take<16 * (i * NT + j) + decltype(RT)::value>(); });
+                acc_read16<16 * (i * NT + j)>(av);
                 // eight pairs, every stage over all of them: independent chains side by side
                 f32x2v x[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    x[k] = f32x2v{av[2 * k], av[2 * k + 1]} + f32x2v{bv[k >> 1][(2 * k) & 3], bv[k >> 1][((2 * k) & 3) + 1]};
+                for (int k = 0; k < 8; ++k) x[k] = f32x2v{av[2 * k], av[2 * k + 1]};  // (the bias is in: the tile started there)
                 if constexpr (GELU) {
                     const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608f, k2 = k1 * 0.044715f;
                     f32x2v t[8];
@@ -537,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                 }
             }
         });
-        asm volatile("s_nop 4" ::: ZG_ACC_CLOBBERS);  // the zeroing v_accvgpr_writes -> the next tile's first MFMAs
+        if (idx + gx < t_end) init_acc_from_bias(tile_par ^ 1);  // the next tile starts at its bias row
         if constexpr (NPEND > 0) {
             pend_row = row0;
             pend_col = col0;
@@ -550,7 +584,6 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         m0 = ntm * 256;
         n0 = ntn * P::BN;
         tile_par ^= 1;
-        fetch_bias(n0, tile_par);
         curA = nxtA;
         curB = nxtB;
         nidx = idx + gx;
@@ -560,6 +593,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
             nxtA = (unsigned)ntm * strideA;
             nxtB = (unsigned)ntn * strideB;
+            fetch_bias(ntn * P::BN, tile_par ^ 1);  // a whole tile ahead of its use (its buffer was last read before this tile began)
         }
     };
     auto advance = [&]() {  // K-step t -> t + 1; true at the end of the tile
@@ -577,6 +611,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // [B of t + 2, A half 1 of t + 1, A half 0 of t + 2]; before K-step 0 that is [B 0, A0 0] and [B 1, A1 0, A0 1].
     {
         fetch_bias(n0, 0);
+        if (nidx < t_end) fetch_bias(ntn * P::BN, 1);
         const Ahead s0 = ahead(0);
         s1 = ahead(1);
         s2 = s1;
@@ -593,6 +628,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         if constexpr (P::PB == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // B and A half 0 of K-step 0 are in
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         bar();
+        init_acc_from_bias(0);  // (wave 0's bias pieces were the first of the stream: landed with the wait above)
         read_kstep_head(Ic<0>{});
     }
 
