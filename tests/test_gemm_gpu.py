@@ -31,7 +31,8 @@ def run_gemm(zg, a, b, bias, gelu, out_bf16):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 128), (128, 256, 768), (256, 3072, 768), (384, 128, 3072), (1024, 768, 768),
-                                   (100, 136, 192), (1000, 200, 128), (1023, 2304, 768), (16, 8, 1600)])
+                                   (100, 136, 192), (1000, 200, 128), (1023, 2304, 768), (16, 8, 1600),
+                                   (64, 126, 128), (300, 131, 192), (257, 7, 128)])  # fp32 output: widths that are not multiples of 4
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gemm_matches_oracle_linear(zg, m, n, k, gelu):
     a = synth.fill_normal(1000 + m, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
@@ -70,16 +71,19 @@ def test_gemm_rejects_unsupported_shapes(zg):
     c = torch.zeros(128 * 128, dtype=torch.float32, device="cuda")
     assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 128, 64, 0, 0) == -5   # K < 128
     assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 128, 100, 0, 0) == -5  # K % 64
-    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 126, 128, 0, 0) == -5  # N % 4
+    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 132, 128, 0, 1) == -5  # bf16 output: N % 8
+    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 126, 128, 0, 0) == 0   # fp32 output: any width
     h = np.zeros(128 * 128, np.uint16)
     assert zg.zg_gemm_bf16_nt(h.ctypes.data, t.data_ptr(), None, c.data_ptr(), 128, 128, 128, 0, 0) == -6
 
 
-@pytest.mark.parametrize("bn,wgs", [(192, 8), (256, 8), (192, 3), (256, 5)])
-def test_gemm_many_tiles_per_workgroup(zg, bn, wgs, monkeypatch):
+@pytest.mark.parametrize("bn,wgs", [(192, 8), (256, 8), (192, 3), (256, 5), (192, 1)])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_gemm_many_tiles_per_workgroup(zg, bn, wgs, out_bf16, monkeypatch):
     """The persistent kernel with few workgroups: every workgroup walks several tiles (tile hand-over with the
-    next tile's operands already in flight, odd K-step counts, ragged edges), both tile widths; repeated runs
-    must agree bit for bit (race screen)."""
+    next tile's operands already in flight, odd K-step counts, ragged edges), both tile widths, both output types
+    (the bf16 epilogue goes through an LDS image); repeated runs must agree bit for bit (race screen: a missing
+    barrier behind the tile hand-over once showed up only with more than two tiles per workgroup)."""
     monkeypatch.setenv("ZGPT2_GEMM_BN", str(bn))
     monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
     m, n, k = 1100, 776, 320
@@ -87,8 +91,12 @@ def test_gemm_many_tiles_per_workgroup(zg, bn, wgs, monkeypatch):
     b = synth.fill_normal(8, n * k, 0.0, 0.05, bf16=True).reshape(n, k)
     bias = synth.fill_normal(9, n, 0.0, 0.5)
     exp = oracle.gelu(oracle.linear_forward(k, n, b, bias, a))
-    runs = [run_gemm(zg, a, b, bias, True, out_bf16=False) for _ in range(3)]
-    assert_ref_close(exp, runs[0], f"gemm bn={bn} wgs={wgs}", scale_floor=4e-6)
+    runs = [run_gemm(zg, a, b, bias, True, out_bf16=out_bf16) for _ in range(6)]
+    if out_bf16:
+        assert np.abs(runs[0] - exp).max() <= 0.01 * np.abs(exp).max()
+        assert np.array_equal(runs[0], synth.round_bf16(run_gemm(zg, a, b, bias, True, out_bf16=False)))
+    else:
+        assert_ref_close(exp, runs[0], f"gemm bn={bn} wgs={wgs}", scale_floor=4e-6)
     assert all(np.array_equal(runs[0], r) for r in runs[1:])
 
 

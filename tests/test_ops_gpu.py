@@ -109,7 +109,8 @@ def test_linear_sweep(zg, m, k, n):
     assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n}", scale_floor=2e-6)
 
 
-@pytest.mark.parametrize("m,k,n", [(1024, 768, 3072), (16, 128, 8), (300, 3072, 768), (1023, 768, 2304), (64, 1600, 6400)])
+@pytest.mark.parametrize("m,k,n", [(1024, 768, 3072), (16, 128, 8), (300, 3072, 768), (1023, 768, 2304), (64, 1600, 6400),
+                                   (16, 768, 50257), (40, 128, 37), (257, 192, 131), (33, 256, 1031)])  # widths that are not multiples of 4
 def test_linear_large_batch_runs_on_the_matrix_cores(zg, m, k, n):
     """Linear.forward with batch >= 16 (ops.zig:22: batch = inputs.len / in_features) takes the MFMA GEMM — fp32
     operands split exactly into bf16 planes — and still meets the reference tolerance against the fp32 oracle."""

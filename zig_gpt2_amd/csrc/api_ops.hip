@@ -141,7 +141,7 @@ struct CallGuard {
 // Order: small products first.
 static bool linear_mfma_ok(size_t in_f, size_t out_f, size_t m, size_t arena_left) {
     static const bool off = getenv("ZGPT2_NO_LINEAR_MFMA") != nullptr;
-    if (off || m < 16 || in_f < 128 || in_f % 64 != 0 || out_f % 4 != 0) return false;
+    if (off || m < 16 || in_f < 128 || in_f % 64 != 0) return false;
     if (m * in_f * 3 >= (1u << 30) || out_f * in_f * 3 >= (1u << 30)) return false;
     return (m + out_f) * in_f * 3 * sizeof(bf16_t) + 1024 <= arena_left;
 }

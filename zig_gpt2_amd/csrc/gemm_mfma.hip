@@ -531,8 +531,11 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     ZG_REQUIRE(M > 0 && N > 0 && pl.kpp >= 2 && pl.npairs >= 1 && pl.npairs <= 8, ZG_ERR_UNSUPPORTED,
                "gemm: M=%d N=%d K=%d pairs=%d: K must be a multiple of 64 and at least 128", M, N, K, pl.npairs);
     ZG_REQUIRE(pl.lda % 8 == 0 && pl.ldb % 8 == 0 && pl.lda >= K && pl.ldb >= K, ZG_ERR_UNSUPPORTED, "gemm: lda=%d ldb=%d", pl.lda, pl.ldb);
-    const int cq = out_bf16 ? 8 : 4;  // output leaves in 16-byte pieces
-    ZG_REQUIRE(N % cq == 0 && ldc >= N && ldc % cq == 0, ZG_ERR_UNSUPPORTED, "gemm: N=%d ldc=%d must be multiples of %d", N, ldc, cq);
+    // bf16 output leaves in 16-byte pieces of 8 columns; fp32 output may have any width and row length (the four-wave kernel
+    // stores a ragged row end dword by dword: Linear 1600 -> 50257 at batch >= 16)
+    const bool ragged = !out_bf16 && (N % 4 != 0 || ldc % 4 != 0);
+    ZG_REQUIRE(ldc >= N && (!out_bf16 || (N % 8 == 0 && ldc % 8 == 0)), ZG_ERR_UNSUPPORTED, "gemm: N=%d ldc=%d (bf16 output: multiples of 8)", N, ldc);
+    ZG_REQUIRE((size_t)M * ldc * (out_bf16 ? 2 : 4) < ((size_t)1 << 32), ZG_ERR_SHAPE, "gemm: output over 4 GiB");
     ZG_REQUIRE((size_t)N * pl.ldb < (1u << 30), ZG_ERR_SHAPE, "gemm: B operand over 2 GiB");
     if ((size_t)M * pl.lda >= (1u << 30)) {
         // The A operand is addressed through a 32-bit buffer descriptor: a taller A goes in row chunks (whole tiles,
@@ -562,7 +565,7 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     // for 256-wide tiles.  ZGPT2_GEMM_KERNEL=p8 / s4 forces one (s4 then always with 192-wide tiles).
     const char* kk = getenv("ZGPT2_GEMM_KERNEL");
     const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8");
-    if (force_s4 || (!force_p8 && bn == 192)) return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, 192, s);
+    if (force_s4 || ragged || (!force_p8 && bn == 192)) return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, 192, s);
     return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
                      : launch_p8_bn<256>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
 }

@@ -547,9 +547,19 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int col = gcol + 8 * g + 4 * hhe;
-                        const unsigned off = (col < N ? row0 + (unsigned)(i * 32) * (unsigned)(ldc * 4) + (unsigned)col * 4u : 0xFFFFFFFFu) | no_store_mask;
+                        const unsigned base_off = row0 + (unsigned)(i * 32) * (unsigned)(ldc * 4) + (unsigned)col * 4u;
+                        const unsigned off = (col + 4 <= N ? base_off : 0xFFFFFFFFu) | no_store_mask;
                         const f32x4v o = {x[2 * g].x, x[2 * g].y, x[2 * g + 1].x, x[2 * g + 1].y};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, 0);
+                        if (N & 3) {  // a row that does not end on a run of four (lm_head: 50257 columns): its last 1-3 columns one by one
+                            const bool tail = col < N && col + 4 > N;
+                            const float oe[3] = {x[2 * g].x, x[2 * g].y, x[2 * g + 1].x};
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) {
+                                const unsigned offe = ((tail && col + e < N) ? base_off + 4u * e : 0xFFFFFFFFu) | no_store_mask;
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(oe[e]), rc, offe, 0, 0);
+                            }
+                        }
                     }
                 }
             });
