@@ -71,6 +71,48 @@ def test_124m_eight_prompts_full_context(zg):
     assert float(top0[i - len(p0), -1] - top0[i - len(p0), -2]) < 1e-4, f"batch 1 and batch 8 diverge at {i}"
 
 
+def test_124m_eight_prompts_fp16_kv_cache(zg, monkeypatch):
+    """The 16-bit KV cache (ZG_GPT_KV_F16: halves the attention traffic of the 8-prompt load) at configs[2]'s per-GPU load
+    over the whole context.  MEASURED: its teacher-forced logits deviate by up to 1.7e-3 of the logit scale from the
+    fp32-cache handle at 1024 positions (11 significant bits per cached element) — outside north_star's 1e-3, which is
+    why fp32 stays the default and the bench's headline; the bound asserted here (2.5e-3) documents the option, and the
+    short-context bound (1e-3 over 64 positions) is in test_gpt_gpu.py.  The 16-byte-load kernel must reproduce the
+    8-byte-load one."""
+    cfg = synth.CONFIGS["124M"]
+    w = synth.make_weights(cfg, seed=7, bf16=True)
+    ctx = cfg.context_size
+    prompts = [synth.rand_tokens(720 + b, 1 + b % 4, cfg.vocab_size) for b in range(8)]
+    m32 = zgpt.GPT(cfg, batch=8)
+    m32.load_weights(w)
+    ids32 = m32.generate(prompts, ctx)
+    m16 = zgpt.GPT(cfg, batch=8, kv_f16=True)
+    m16.load_weights(w)
+    ids16 = m16.generate(prompts, ctx)
+    # teacher-forced logits of both handles on the fp32 handle's tokens, at positions spread over the context
+    worst = 0.0
+    for s in range(ctx):
+        want = s in (0, 1, 63, 64, 255, 256, 511, 777, 1023)
+        toks = [int(ids32[b, s]) for b in range(8)]
+        l32 = m32.forward(s + 1, toks, compute_logits=want)
+        l16 = m16.forward(s + 1, toks, compute_logits=want)
+        if want:
+            for b in range(8):
+                rms = float(np.sqrt(np.mean(l32[b].astype(np.float64) ** 2)))
+                worst = max(worst, float(np.abs(l16[b] - l32[b]).max()) / rms)
+    assert worst <= 2.5e-3, f"fp16 KV cache: worst logit deviation {worst:.2e} of the logit scale"
+    print(f"fp16 KV cache at 124M x 8 x 1024: worst logit deviation {worst:.2e} of the logit scale")
+    agree = float((ids16 == ids32).mean())
+    assert agree > 0.5, agree  # a greedy run may leave the fp32 run's path at a near-tie and never return: ids are checked teacher-forced above
+    m32.close()
+    monkeypatch.setenv("ZGPT2_NO_KV_H8", "1")
+    m8 = zgpt.GPT(cfg, batch=8, kv_f16=True)
+    m8.load_weights(w)
+    ids8 = m8.generate(prompts, 256)
+    m8.close()
+    m16.close()
+    assert float((ids8 == ids16[:, :256]).mean()) > 0.9  # (the two load shapes sum in another order: identical ids are the rule, not the contract)
+
+
 def test_xl_full_size(zg):
     """GPT-2 XL at full size: 48 layers of E = 1600 (K = 1600 / 6400 kernels, 25 heads), lm_head 1600 -> 50257."""
     cfg = synth.CONFIGS["xl"]

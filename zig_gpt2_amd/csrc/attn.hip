@@ -13,6 +13,8 @@
 // probabilities are handed back to the lanes that hold the matching V rows with DPP row broadcasts.
 // Four waves (256 positions) are merged in LDS; partials (o[64], m, l) of the <= ctx/256 splits
 // per head are combined by the consumer (the c_proj GEMV prologue, or attn_merge_kernel).
+#include <stdlib.h>
+
 #include "zg_kernels.h"
 
 namespace zg {
@@ -183,6 +185,143 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
 }
 
+// ---- fp16 cache: 16-byte loads.  A 128-byte row (64 halves) is covered by EIGHT lanes of 8 halves each, so a load
+// instruction of the wave covers 8 positions and the 64 positions of a wave need 8 + 8 loads of 16 B (the first fp16 path
+// kept the fp32 lane map: 8-byte loads, twice the load instructions for the same bytes — and lost to the fp32 cache).
+// Lane (g8 = lane / 8, c = lane % 8): dims 8 c .. 8 c + 7 of positions base + 8 i + g8, i = 0..7.  The partial dots are
+// reduce-scattered over the 8 lanes of a group (lane c ends with the score of position base + 8 c + g8), the softmax
+// statistics are wave reductions as above, p goes back to the group with two row broadcasts and a select.
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+
+__device__ __forceinline__ float grp8_reduce_scatter(float (&s)[8], int c) {
+    float a4[4];
+    {
+        const bool hi = c & 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = hi ? s[j + 4] : s[j];
+            const float send = hi ? s[j] : s[j + 4];
+            const float from_lo = dpp_row_ror<4>(send);   // from lane - 4
+            const float from_hi = dpp_row_ror<12>(send);  // from lane + 4
+            a4[j] = keep + (hi ? from_lo : from_hi);
+        }
+    }
+    float a2[2];
+    {
+        const bool hi = c & 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = hi ? a4[j + 2] : a4[j];
+            const float send = hi ? a4[j] : a4[j + 2];
+            const float from_lo = dpp_row_ror<2>(send);
+            const float from_hi = dpp_row_ror<14>(send);
+            a2[j] = keep + (hi ? from_lo : from_hi);
+        }
+    }
+    const bool hi = c & 1;
+    const float keep = hi ? a2[1] : a2[0];
+    const float send = hi ? a2[0] : a2[1];
+    const float from_lo = dpp_row_ror<1>(send);
+    const float from_hi = dpp_row_ror<15>(send);
+    return keep + (hi ? from_lo : from_hi);
+}
+
+__global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_o[4][64];
+    __shared__ float s_m[4], s_l[4];
+    const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const int t_hi = a.t_hi;
+    const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
+    const int chunk0 = split * kAttnChunk;
+    if (chunk0 >= t_hi) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 7, g8 = lane >> 3;
+    const int base = chunk0 + wave * 64;
+    const _Float16* K = reinterpret_cast<const _Float16*>(a.k) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+    const _Float16* V = reinterpret_cast<const _Float16*>(a.v) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+    const float* qp = a.q + ((size_t)b * a.n_heads + h) * 64 + c * 8;
+    const f32x4 qa = *reinterpret_cast<const f32x4*>(qp), qb = *reinterpret_cast<const f32x4*>(qp + 4);
+    const float q[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const float alpha = 0.125f;
+
+    float m_w = kNegBig, l_w = 0.0f;
+    float o[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (base < t_hi) {
+        h8 k8[8], v8[8];
+        const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = base + 8 * i + g8;
+            if (t < t_hi) {
+                k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * a.stride_t + c * 8);
+                v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * a.stride_t + c * 8);
+            } else {
+                k8[i] = zero8;
+                v8[i] = zero8;
+            }
+        }
+        pf_count(a.progress);
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(q[e], (float)k8[i][e], acc);
+            s[i] = acc;
+        }
+        float sc = grp8_reduce_scatter(s, c) * alpha;  // lane (g8, c): position base + 8 c + g8
+        const int t_mine = base + 8 * c + g8;
+        if (t_mine >= T) sc = kNegBig;
+        m_w = wave_allmax(sc);
+        const float p = (t_mine < T) ? __expf(sc - m_w) : 0.0f;
+        l_w = wave_allsum(p);
+        // p of position (i, g8) lives in lane 8 g8 + i: lanes 0-7 of a 16-lane row need lane i of the row, lanes 8-15 lane 8 + i
+        const bool up = lane & 8;
+#define ZG_PV8(i)                                                                                                          \
+    {                                                                                                                      \
+        const float plo = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x150 + (i), 0xF, 0xF, false));     \
+        const float phi = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x150 + 8 + (i), 0xF, 0xF, false)); \
+        const float pi = up ? phi : plo;                                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = fmaf(pi, (float)v8[i][e], o[e]);                              \
+    }
+        ZG_PV8(0) ZG_PV8(1) ZG_PV8(2) ZG_PV8(3) ZG_PV8(4) ZG_PV8(5) ZG_PV8(6) ZG_PV8(7)
+#undef ZG_PV8
+        // sum the eight position groups: lanes 8, 16 and 32 apart
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] += dpp_row_ror<8>(o[e]);
+            o[e] += __shfl_xor(o[e], 16, 64);
+            o[e] += __shfl_xor(o[e], 32, 64);
+        }
+    }
+    if (lane < 8) {
+        *reinterpret_cast<f32x4*>(&s_o[wave][lane * 8]) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(&s_o[wave][lane * 8 + 4]) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+    if (lane == 0) {
+        s_m[wave] = m_w;
+        s_l[wave] = l_w;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float ov = 0.0f, l = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __expf(s_m[w] - M);
+            ov = fmaf(sc, s_o[w][lane], ov);
+            l = fmaf(sc, s_l[w], l);
+        }
+        float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
+        part[lane] = ov;
+        if (lane == 0) {
+            part[64] = M;
+            part[65] = l;
+        }
+    }
+}
+
 // Standalone combine of the split partials (op tier; the model tier folds this into c_proj).
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* part, int n_heads, int max_splits,
                                                          int seq_len, float* out) {
@@ -211,7 +350,9 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     const int splits = (a.t_hi + kAttnChunk - 1) / kAttnChunk;
     ZG_REQUIRE(splits <= a.max_splits, ZG_ERR_ARG, "attention: t_hi %d needs %d splits > %d", a.t_hi, splits, a.max_splits);
     dim3 grid(a.n_heads, splits, a.batch);
-    if (a.kv_f16) hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a);
+    static const bool h8_off = getenv("ZGPT2_NO_KV_H8") != nullptr;  // A/B: the fp16 cache on the fp32 lane map (8-byte loads)
+    if (a.kv_f16 && a.stride_t == 64 && !h8_off) hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a);
+    else if (a.kv_f16) hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
