@@ -138,12 +138,18 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
             m.forward(t0 + i, tok, True)
         return (time.perf_counter() - t) / n
 
-    # choose the faster of the built-in SGEMM and a real CBLAS (if one can be dlopen'ed) on a short probe
+    # BASELINE configs[0]: 1 prompt, 64 tokens (positions 1..64), with each SGEMM available: the built-in OpenMP one and a
+    # real CBLAS if one can be dlopen'ed on this box (the reference links Accelerate / OpenBLAS, build.zig:28-32)
+    t64 = {}
     t_builtin = window(1, 4)
+    t64["built-in OpenMP sgemm"] = window(1, 64)
+    blas_found = None
     if found and oracle.use_cblas(found[0], found[1]) == 0:
+        blas_found = found[2]
         t_blas = window(1, 4)
+        t64[blas_found] = window(1, 64)
         if t_blas < t_builtin:
-            blas = found[2]
+            blas = blas_found
         else:
             oracle.use_cblas(None)
     n_win = max(8, int(budget_s / 2 / max(min(t_builtin, 1.0), 1e-3) / 1.5))
@@ -166,6 +172,8 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
     return {
         "value": round(1.0 / mean_cost, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
         "cpu_model": cpu_model, "visible_cpus": os.cpu_count(), "blas": blas,
+        "cblas_found": blas_found if blas_found else "not found (no libopenblas / libcblas to dlopen on this box)",
+        "first_64_tokens_tokens_per_s": {k: round(1.0 / v, 2) for k, v in t64.items()},
         "sample": f"oracle GPT.forward fp32, {blas}: {n_win} tokens at T={lo0}.. ({1e3 * t_lo:.1f} ms/tok) and "
                   f"{n_win} at T={hi0}.. ({1e3 * t_hi:.1f} ms/tok); whole 1..{ctx} run priced by the affine fit",
     }
@@ -301,6 +309,11 @@ def main():
     tot_us = sum(r["us_per_token"] for r in table)
     for r in table:
         r["share_of_token_time"] = round(r["us_per_token"] / tot_us, 4)
+    sym1 = {1: "gemv_lnk_kernel", 2: "attn_decode_h8_kernel" if a.kv_f16 else "attn_decode_kernel<float>", 3: "gemv_kernel (PRO_ATTN_MERGE)",
+            4: "gemv_lnk_kernel", 5: "gemv_ksplit_kernel", 6: "gemv_kernel (ARGMAX)"}
+    symn = {1: "gemv_mfma_kernel", 2: sym1[2], 3: "gemv_mfma_kernel", 4: "gemv_mfma_kernel", 5: "gemv_mfma_kernel (KSL = 4)", 6: "lm_head_wpt_kernel"}
+    for r, (which, _, _, _) in zip(table, classes):
+        r["kernel_symbol"] = (sym1 if ppg == 1 else symn)[which]
     dom = max(table, key=lambda r: r["us_per_token"])
     lm = table[-1]
     n_prof = min(64, ctx)
@@ -390,9 +403,12 @@ def main():
             "tokens_counted": "generated tokens (context - prompt) per prompt",
         },
         "roofline": {
-            "kernel": dom["class"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": dom["class"], "kernel_symbol": dom["kernel_symbol"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac_of_8TBps"], "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
+            "avg_launch_us_layers_walked": dom["avg_launch_us_layers_walked"],
+            "achieved_layers_walked": round(dom["algorithmic_bytes_per_launch"] / dom["avg_launch_us_layers_walked"] / 1e3, 1),
+            "frac_layers_walked": round(dom["algorithmic_bytes_per_launch"] / dom["avg_launch_us_layers_walked"] / 1e3 / HBM_PEAK_GBS, 4),
             "share_of_token_time": dom["share_of_token_time"],
             "how": "the kernel class with the largest share of the decode-step time; duration = HIP events on the launch "
                    "stream around a hipGraph chain of that kernel (launch boundary included), measured in this run; "

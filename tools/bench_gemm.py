@@ -21,18 +21,22 @@ def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
     for _ in range(400):  # the chip needs tens of milliseconds under load before its clocks settle
         run()
     torch.cuda.synchronize()
-    us = 1e30
-    for _ in range(5):  # best of five timed batches
+    batches = []
+    for _ in range(5):  # five timed batches: the MEAN is the headline, the minimum is printed beside it
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(iters):
             run()
         e1.record(stream)
         torch.cuda.synchronize()
-        us = min(us, e0.elapsed_time(e1) * 1e3 / iters)
+        batches.append(e0.elapsed_time(e1) * 1e3 / iters)
+    us, us_min = sum(batches) / len(batches), min(batches)
     flops = 2.0 * m * n * k
-    return {"M": m, "N": n, "K": k, "us": round(us, 2), "tflops": round(flops / us / 1e6, 1),
-            "mfma_frac_of_2.5PF": round(flops / us / 1e6 / PEAK_TF, 4), "gelu": gelu, "out": "bf16" if out_bf16 else "f32",
+    return {"M": m, "N": n, "K": k, "us": round(us, 2), "us_min": round(us_min, 2), "tflops": round(flops / us / 1e6, 1),
+            "mfma_frac_of_2.5PF": round(flops / us / 1e6 / PEAK_TF, 4), "mfma_frac_of_2.5PF_best_batch": round(flops / us_min / 1e6 / PEAK_TF, 4),
+            "timing": "mean of five batches of %d back-to-back launches (HIP events on the launch stream) after 400 warm-up launches; us_min = best batch" % iters,
+            "kernel": os.environ.get("ZGPT2_GEMM_KERNEL", "default (gemm_s4_kernel for 192-wide tiles, gemm_p8_kernel for 256-wide)"),
+            "gelu": gelu, "out": "bf16" if out_bf16 else "f32",
             "bytes_min": (m * k + n * k) * 2 + m * n * (2 if out_bf16 else 4)}
 
 
