@@ -124,7 +124,7 @@ int zg_softmax(float* inputs, size_t inputs_len);
  * optional fused GELU — the same contraction as Linear.forward's cblas_sgemm(NoTrans, Trans)
  * (src/ops.zig:30-45) for large batch (prefill), with both operands in ops.Linear's K-contiguous
  * layouts.  A, B are bf16 bit patterns and C is bf16 (out_bf16 != 0) or fp32, all DEVICE pointers;
- * any M, N a multiple of 8 (bf16 C) or 4 (fp32 C), K a multiple of 64 and at least 128.  Asynchronous on
+ * any M; N a multiple of 8 for bf16 C, any N for fp32 C; K a multiple of 64 and at least 128.  Asynchronous on
  * the library stream.  zg_linear_forward itself takes this path for batch >= 16 (fp32 operands split
  * exactly into bf16 planes, so the result stays fp32-sgemm grade).
  * zg_f32_to_bf16 converts a device or host fp32 array into a device bf16 array (round to nearest even). */
@@ -198,7 +198,9 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
  * (Linears as matrix-core GEMMs, causal attention), filling the KV caches exactly as n_tokens calls of
  * zg_gpt_forward would.  tokens is [batch][token_stride].  With compute_logits != 0 the logits of position
  * n_tokens-1 are produced as zg_gpt_forward(n_tokens, ...) would (zg_gpt_argmax / logits_out as there).
- * Afterwards decoding continues with zg_gpt_forward(n_tokens + 1, ...).  bf16-weight handles only. */
+ * Afterwards decoding continues with zg_gpt_forward(n_tokens + 1, ...).  Both weight modes: bf16-weight handles multiply the
+ * exact three-plane split of the activations with the weights, ZG_GPT_WEIGHTS_F32 handles split both operands (six plane
+ * products: fp32-sgemm grade).  Not available on handles created with ZG_GPT_NO_PREFILL. */
 int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t n_tokens,
                    int compute_logits, float* logits_out, size_t logits_len);
 /* argmax of the logits of the last zg_gpt_forward(compute_logits=1) per sequence (lowest index
