@@ -56,6 +56,10 @@ struct zg_gpt {
     float *pf_x, *pf_qkv, *pf_ws;
     size_t pf_ws_floats;
     bf16_t *pf_a, *pf_h;
+    // lock-step batch with bf16 weights: activation planes between the kernels of a Block (GemvArgs.pl_in / pl_out):
+    // xp = planes of g * x for the next LayerNorm-fed Linear [48 E bytes], hp = planes of gelu(c_fc) [48 * 4E bytes]
+    bf16_t *xp, *hp;
+    bool pl_on;
     int max_splits, lm_grid;
     // pinned host mirrors for small control traffic
     StepCtrl* h_ctrl;
@@ -155,9 +159,11 @@ void carve(zg_gpt* g, char* base) {
     g->forced = (int*)P(B * 4);
     g->cur_token = (int*)P(B * 4);
     g->out_tokens = (int*)P(B * C * 4);
+    g->xp = (bf16_t*)P(E * 48);
+    g->hp = (bf16_t*)P(4 * E * 48);
     g->sk_tiles = (int)((E + 15) / 16);
     g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
-    g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4);
+    g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4 * 4);  // [tile][4]: the four-wave plane-fed kernel takes one ticket per wave
     g->pf_njobs = (int)(2 + 5 * L);
     g->pf_ctl = (PfCtl*)P(sizeof(PfCtl));
     g->pf_jobs = (PfJob*)P((size_t)g->pf_njobs * sizeof(PfJob));
@@ -226,6 +232,8 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.part_stride = g->lm_grid;  // the lm_head GEMV writes partials [batch][gridDim.x]
     e.n_partials = g->lm_grid;
     e.x = g->x;
+    e.pl_out = g->pl_on ? g->xp : nullptr;
+    e.pl_g = g->layers[0].ln_1_g;
     e.finish_only = finish_only;
     e.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
     return e;
@@ -338,6 +346,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.ln_c2 = y.c_attn_c2;
             a.ln_c3 = y.c_attn_c3;
             a.epilogue = EPI_QKV;
+            a.pl_in = g->pl_on ? g->xp : nullptr;
             a.q = g->q;
             a.k_cache = y.k_cache;
             a.v_cache = y.v_cache;
@@ -386,6 +395,10 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y_stride = (int)E;
             a.resid = g->x;
             a.resid_stride = (int)E;
+            if (g->pl_on) {
+                a.pl_out = g->xp;
+                a.pl_g = y.ln_2_g;
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 3));
             ZG_TRY(prof_mark(prof, 3, s));
@@ -402,6 +415,11 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.epilogue = EPI_GELU;
             a.y = g->h4;
             a.y_stride = (int)(4 * E);
+            if (g->pl_on) {  // gelu(c_fc) leaves as planes only
+                a.pl_in = g->xp;
+                a.pl_out = g->hp;
+                a.y = nullptr;
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 4));
             ZG_TRY(prof_mark(prof, 4, s));
@@ -416,6 +434,13 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y_stride = (int)E;
             a.resid = g->x;
             a.resid_stride = (int)E;
+            if (g->pl_on) {
+                a.pl_in = g->hp;
+                if (l + 1 < g->cfg.n_layer) {  // the next Block's ln_1 + c_attn (ln_f + lm_head reads x itself)
+                    a.pl_out = g->xp;
+                    a.pl_g = g->layers[l + 1].ln_1_g;
+                }
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 5));
             ZG_TRY(prof_mark(prof, 5, s));
@@ -756,6 +781,28 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
                       batch, c.n_embed, batch);
             return ZG_ERR_UNSUPPORTED;
         }
+    }
+    g->pl_on = false;
+    if (g->wt == WT_BF16 && batch >= 2 && !env_int("ZGPT2_NO_PLANES", 0)) {  // all three plane-fed Linears on the matrix-core path?
+        const zg_layer& y = g->layers[0];
+        GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, 0);
+        a1.prologue = PRO_LAYERNORM;
+        a1.ln_c2 = y.c_attn_c2;
+        a1.ln_c3 = y.c_attn_c3;
+        a1.epilogue = EPI_QKV;
+        GemvArgs a4 = base_gemv(g, y.c_fc_w, y.c_fc_b, 4 * c.n_embed, c.n_embed, 0);
+        a4.prologue = PRO_LAYERNORM;
+        a4.ln_c2 = y.c_fc_c2;
+        a4.ln_c3 = y.c_fc_c3;
+        a4.epilogue = EPI_GELU;
+        GemvArgs a5 = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, c.n_embed, 4 * c.n_embed, 0);
+        a5.prologue = PRO_NONE;
+        a5.epilogue = EPI_RESIDUAL;
+        GemvArgs a3 = base_gemv(g, y.c_proj_w, y.c_proj_b, c.n_embed, c.n_embed, 0);
+        a3.prologue = PRO_ATTN_MERGE;
+        a3.epilogue = EPI_RESIDUAL;
+        g->pl_on = c.n_embed % 32 == 0 && gemv_planes_ok(a1, g->wt) && gemv_planes_ok(a4, g->wt) && gemv_planes_ok(a5, g->wt) &&
+                   gemv_supported(a3, g->wt) && gemv_planes_producer_ok(a3, g->wt);
     }
     if (g->lm_grid > 4096) {
         (void)hipFree(g->arena);

@@ -223,6 +223,15 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
             o = t + p;
         }
         *reinterpret_cast<f32x4*>(a.x + (size_t)b * a.n_embed + e) = o;
+        if (a.pl_out) {  // the first Linear of the lock-step batch reads its input as planes of g * x
+            const f32x4 v = o * *reinterpret_cast<const f32x4*>(a.pl_g + e);
+            uint32_t h0, m0, l0, h1, m1, l1;
+            split3_pk(v.x, v.y, h0, m0, l0);
+            split3_pk(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(0, b, e)) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(1, b, e)) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(2, b, e)) = u32x2{l0, l1};
+        }
     }
     if (threadIdx.x == 0 && a.finish_only == 0) {
         a.ctrl->seq_len = s + 1;

@@ -136,18 +136,20 @@ __device__ __forceinline__ void kv_store(void* cache, size_t off, float v) {
 }
 
 // bias_n / resid_mn were fetched together with the row's weights (no dependent round trip here).
-__device__ __forceinline__ void epilogue_row(const GemvArgs& a, int m, int n, float acc, float bias_n,
-                                             float resid_mn, int pos, Best& best) {
+__device__ __forceinline__ float epilogue_row(const GemvArgs& a, int m, int n, float acc, float bias_n,
+                                              float resid_mn, int pos, Best& best) {
     float v = acc + bias_n;
     switch (a.epilogue) {
         case EPI_STORE:
             a.y[(size_t)m * a.y_stride + n] = v;
             break;
         case EPI_RESIDUAL:
-            a.y[(size_t)m * a.y_stride + n] = v + resid_mn;
+            v += resid_mn;
+            a.y[(size_t)m * a.y_stride + n] = v;
             break;
         case EPI_GELU:
-            a.y[(size_t)m * a.y_stride + n] = gelu_ref(v);
+            v = gelu_ref(v);
+            if (a.y) a.y[(size_t)m * a.y_stride + n] = v;  // null: the output leaves as planes only (GemvArgs.pl_out)
             break;
         case EPI_QKV: {
             const int E = a.N / 3;
@@ -156,7 +158,14 @@ __device__ __forceinline__ void epilogue_row(const GemvArgs& a, int m, int n, fl
             } else {
                 const int which = n >= 2 * E;
                 const int e = n - (which ? 2 * E : E);
-                const int h = e / a.head_dim, d = e % a.head_dim;
+                int h, d;
+                if (a.head_dim == 64) {  // the GPT-2 family: no integer division in the epilogue
+                    h = e >> 6;
+                    d = e & 63;
+                } else {
+                    h = e / a.head_dim;
+                    d = e % a.head_dim;
+                }
                 const size_t off = (((size_t)m * a.n_heads + h) * a.ctx + pos) * a.head_dim + d;
                 void* cache = which ? a.v_cache : a.k_cache;
                 if (a.kv_f16) kv_store<_Float16>(cache, off, v);
@@ -173,6 +182,7 @@ __device__ __forceinline__ void epilogue_row(const GemvArgs& a, int m, int n, fl
             break;
         }
     }
+    return v;
 }
 
 // Merged attention output for elements [e0, e0+4) of sequence m: all loads issued before any math.
@@ -1024,7 +1034,12 @@ __device__ __forceinline__ void store_split4(char* planes, int S, int m, int k, 
 // fragment layout itself puts 16 different rows into the 16 lanes of a group, i.e. half a line per row per
 // instruction, which costs 0.5..0.8 us per launch at 124M and 1.2..2.3 us at GPT-2 XL (8 sequences).  A wave then owns
 // PAIRS of 32-k steps (wave + NW i); needs K % 64 == 0 and room for the slots.
-template <int KS, int NW, bool ARGMAX, int KSL = 1, bool LINE = false>
+// GPL: the input rows arrive as planes in global memory, written by the previous kernel's epilogue (GemvArgs.pl_in,
+// layout zg_common.h plane_elem): every lane loads the A fragments of its own 32-k steps straight into registers next
+// to the weights — no LDS planes, no split and no barrier in front of the MFMAs (that prologue, repeated by every
+// workgroup for all 8 rows, was 55-60 % of these kernels).  With the folded LayerNorm only the row statistics are
+// summed from x, beside the loads, and reach wave 0 through the exchange barrier of the first tile.
+template <int KS, int NW, bool ARGMAX, int KSL = 1, bool LINE = false, bool GPL = false>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __restrict__ W, const float* __restrict__ xin,
                                                             int N, int K, int M, int tiles_per_wg, int prologue,
                                                             int epilogue, const float* __restrict__ ln_g,
@@ -1041,8 +1056,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq = K >> 2, nsteps = K >> 5;
     const int S = 2 * K + 16;
-    char* planes = smem_mf;                                                       // [3][8][S]
-    float* red = reinterpret_cast<float*>(smem_mf + (size_t)3 * kMfmaRows * S);  // LN partial sums, then partial tiles
+    static_assert(!GPL || (!ARGMAX && NW == 16), "global planes: the per-layer Linears only");
+    char* planes = smem_mf;                                                       // [3][8][S] (not with GPL)
+    float* red = reinterpret_cast<float*>(smem_mf + (GPL ? (size_t)0 : (size_t)3 * kMfmaRows * S));  // LN partial sums, then partial tiles
     const int ntiles = (N + 15) >> 4;
     const int tile_begin = blockIdx.x * tiles_per_wg;
     const int tile_end = min(tile_begin + tiles_per_wg, ntiles);
@@ -1079,10 +1095,30 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     ZG_STAMP(1);
     // bias / residual of the FIRST tile are fetched here, next to the weights, instead of one more
     // dependent L2 round trip inside the epilogue
-    float pre_bias = 0.0f, pre_res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // GPL: A fragments of this wave's steps, all three planes; tile rows 8..15 have no batch row behind them: zeros
+    constexpr int NAF = GPL ? (LINE ? 2 * KP : KS) * 3 : 1;
+    u32x4 af[NAF];
+    if constexpr (GPL) {
+        const bf16_t* pin = a.pl_in + (KSL > 1 ? (size_t)blockIdx.y * nsteps * kPlaneStep : (size_t)0) + (lane & 7) * 32 + bq * 8;
+#pragma unroll
+        for (int i = 0; i < NAF / 3; ++i) {
+            const int st = LINE ? 2 * min(wave + NW * (i >> 1), npairs - 1) + (i & 1) : min(wave + NW * i, nsteps - 1);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[i * 3 + p] = u32x4{0u, 0u, 0u, 0u};
+                if ((lane & 8) == 0) af[i * 3 + p] = *reinterpret_cast<const u32x4*>(pin + (size_t)(st * 3 + p) * 256);
+            }
+        }
+    }
+    float pre_bias = 0.0f, pre_res[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pre_g = 1.0f, pre_c2 = 0.0f, pre_c3 = 0.0f;
     if (wave == 0) {
         const int n = min(min(tile_begin, ntiles - 1) * 16 + brow, N - 1);
         if (a.bias) pre_bias = a.bias[n];
+        if (a.pl_out && a.pl_g) pre_g = a.pl_g[n];
+        if (GPL && prologue == PRO_LAYERNORM) {
+            pre_c2 = a.ln_c2[n];
+            pre_c3 = a.ln_c3[n];
+        }
         if (epilogue == EPI_RESIDUAL)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pre_res[r] = a.resid[(size_t)min(bq * 4 + r, M - 1) * a.resid_stride + n];
@@ -1106,7 +1142,33 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     // statistics that were summed alongside.
     // (not for the vocabulary-wide form: its per-tile c2 / c3 fetches cost more than the one prologue barrier saves)
     const bool lin_ln = !ARGMAX && kHasLn && prologue == PRO_LAYERNORM && a.ln_c2 != nullptr;
-    if (lin_ln) {
+    if constexpr (GPL) {
+        if (lin_ln) {  // row statistics only
+            f32x4 v[RPW][JT];
+#pragma unroll
+            for (int t = 0; t < JT; ++t)
+#pragma unroll
+                for (int j = 0; j < RPW; ++j)
+                    v[j][t] = reinterpret_cast<const f32x4*>(xin + (size_t)min(row_of(j), M - 1) * a.x_stride)[min(cidx[t], nq - 1)];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int m = row_of(j);
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int t = 0; t < JT; ++t) {
+                    if (cidx[t] >= c1 || m >= M) v[j][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    t1 += (v[j][t].x + v[j][t].y) + (v[j][t].z + v[j][t].w);
+                    t2 = fmaf(v[j][t].x, v[j][t].x, fmaf(v[j][t].y, v[j][t].y, fmaf(v[j][t].z, v[j][t].z, fmaf(v[j][t].w, v[j][t].w, t2))));
+                }
+                t1 = wave_allsum(t1);
+                t2 = wave_allsum(t2);
+                if (lane == 0) {
+                    red[(m * PARTS + part) * 2] = t1;
+                    red[(m * PARTS + part) * 2 + 1] = t2;
+                }
+            }
+        }
+    } else if (lin_ln) {
         f32x4 v[RPW][JT], g4[JT];
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -1217,7 +1279,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
                 if (cidx[t] < c1) store_split4(planes, S, m, cidx[t] * 4, (m < M) ? o[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f});
         }
     }
-    __syncthreads();
+    if constexpr (!GPL) __syncthreads();
     ZG_STAMP(3);
 
     // ---- 2. tiles: the NW waves split K (wave w takes the 32-k steps w, w + NW, ...) and combine their
@@ -1230,7 +1292,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
     }
     const int pos = T - 1;
     float ln_mu[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ln_rs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    if (lin_ln && wave == 0) {  // rows m = 4 bq + r of this lane
+    auto ln_stats = [&]() {  // rows m = 4 bq + r of this lane
         const float inv_k = 1.0f / (float)K;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1244,7 +1306,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
             ln_mu[r] = s1 * inv_k;
             ln_rs[r] = __builtin_amdgcn_rsqf(s2 * inv_k - ln_mu[r] * ln_mu[r] + a.eps);
         }
-    }
+    };
+    if (!GPL && lin_ln && wave == 0) ln_stats();
     const size_t plane = (size_t)kMfmaRows * S;
     const char* arow = planes + (size_t)(lane & 7) * S + bq * 16;  // A fragment: batch row (lane & 15) & 7
     // [2 buffers][NW waves][64 lanes][4].  When the planes alone nearly fill the LDS (K = 3072: 148 KiB) and the
@@ -1277,8 +1340,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
                 const mf_bf16x8 b0 = __builtin_bit_cast(mf_bf16x8, v0), b1 = __builtin_bit_cast(mf_bf16x8, v1);
 #pragma unroll
                 for (int p = 2; p >= 0; --p) {  // smallest plane first
-                    const mf_bf16x8 a0 = *reinterpret_cast<const mf_bf16x8*>(arow + p * plane + (2 * qc) * 64);
-                    const mf_bf16x8 a1 = *reinterpret_cast<const mf_bf16x8*>(arow + p * plane + (2 * qc + 1) * 64);
+                    mf_bf16x8 a0, a1;
+                    if constexpr (GPL) {
+                        a0 = __builtin_bit_cast(mf_bf16x8, af[(2 * i) * 3 + p]);
+                        a1 = __builtin_bit_cast(mf_bf16x8, af[(2 * i + 1) * 3 + p]);
+                    } else {
+                        a0 = *reinterpret_cast<const mf_bf16x8*>(arow + p * plane + (2 * qc) * 64);
+                        a1 = *reinterpret_cast<const mf_bf16x8*>(arow + p * plane + (2 * qc + 1) * 64);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
                 }
@@ -1292,9 +1361,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
                 u32x4 wv = wq[i];
                 if (st >= nsteps) wv = u32x4{0u, 0u, 0u, 0u};
                 const mf_bf16x8 b = __builtin_bit_cast(mf_bf16x8, wv);
-                const mf_bf16x8 a_lo = *reinterpret_cast<const mf_bf16x8*>(arow + 2 * plane + stc * 64);
-                const mf_bf16x8 a_mid = *reinterpret_cast<const mf_bf16x8*>(arow + plane + stc * 64);
-                const mf_bf16x8 a_hi = *reinterpret_cast<const mf_bf16x8*>(arow + stc * 64);
+                mf_bf16x8 a_lo, a_mid, a_hi;
+                if constexpr (GPL) {
+                    a_lo = __builtin_bit_cast(mf_bf16x8, af[i * 3 + 2]);
+                    a_mid = __builtin_bit_cast(mf_bf16x8, af[i * 3 + 1]);
+                    a_hi = __builtin_bit_cast(mf_bf16x8, af[i * 3]);
+                } else {
+                    a_lo = *reinterpret_cast<const mf_bf16x8*>(arow + 2 * plane + stc * 64);
+                    a_mid = *reinterpret_cast<const mf_bf16x8*>(arow + plane + stc * 64);
+                    a_hi = *reinterpret_cast<const mf_bf16x8*>(arow + stc * 64);
+                }
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, b, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
@@ -1303,17 +1379,25 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
         if (tile == tile_begin) ZG_STAMP(4);
         if (tile + 1 < tile_end) load_tile(tile + 1);  // next tile's weights fly under the epilogue
         if (alias_partial) __syncthreads();  // all A fragments consumed: the plane area becomes the exchange buffer
-        *reinterpret_cast<mf_f32x4*>(partial + ((buf * NW + wave) * 64 + lane) * 4) = acc;
+        if constexpr (GPL) {  // lanes 32..63 (tile rows 8..15) hold zeros: half-size partial tiles
+            if (lane < 32) *reinterpret_cast<mf_f32x4*>(partial + ((buf * NW + wave) * 32 + lane) * 4) = acc;
+        } else {
+            *reinterpret_cast<mf_f32x4*>(partial + ((buf * NW + wave) * 64 + lane) * 4) = acc;
+        }
         __syncthreads();
         if (tile == tile_begin) ZG_STAMP(5);
         if (wave == 0) {
+            if (GPL && lin_ln && tile == tile_begin) ln_stats();
             // lanes 32..63 hold duplicates of lanes 0..31 (tile rows 8..15 alias the batch rows 0..7): with 16
             // waves each half of the wave sums 8 of the partial tiles, one cross-half exchange adds the two
             constexpr int NSUM = NW == 16 ? 8 : NW;
             const int w0 = NW == 16 ? (lane >> 5) * 8 : 0;
             mf_f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int w = 0; w < NSUM; ++w) sum += *reinterpret_cast<const mf_f32x4*>(partial + ((buf * NW + w0 + w) * 64 + lane) * 4);
+            for (int w = 0; w < NSUM; ++w) {
+                if constexpr (GPL) sum += *reinterpret_cast<const mf_f32x4*>(partial + ((buf * NW + w0 + w) * 32 + (lane & 31)) * 4);
+                else sum += *reinterpret_cast<const mf_f32x4*>(partial + ((buf * NW + w0 + w) * 64 + lane) * 4);
+            }
             if (NW == 16) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], 32, 64);
@@ -1356,7 +1440,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
                 const bool first = KSL == 1 && tile == tile_begin;
                 float bias_n = first ? pre_bias : (a.bias ? a.bias[n] : 0.0f);
                 if (lin_ln) {  // y = r_m (S1 - mu_m c2_n) + c3_n; c3 already holds the bias
-                    const float c2n = a.ln_c2[n], c3n = a.ln_c3[n];
+                    const float c2n = (GPL && first) ? pre_c2 : a.ln_c2[n], c3n = (GPL && first) ? pre_c3 : a.ln_c3[n];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sum[r] = fmaf(ln_rs[r], fmaf(-ln_mu[r], c2n, sum[r]), c3n);
                     bias_n = 0.0f;
@@ -1367,7 +1451,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
                     if (m < M) {
                         const float res = first ? pre_res[r]
                                                 : ((epilogue == EPI_RESIDUAL) ? a.resid[(size_t)m * a.resid_stride + n] : 0.0f);
-                        epilogue_row(a, m, n, sum[r], bias_n, res, pos, best[ARGMAX ? r : 0]);
+                        sum[r] = epilogue_row(a, m, n, sum[r], bias_n, res, pos, best[ARGMAX ? r : 0]);
+                    }
+                }
+                if (!ARGMAX && a.pl_out) {  // the next Linear reads these rows as planes (of g * y when a LayerNorm follows)
+                    const float gn = a.pl_g ? (tile == tile_begin ? pre_g : a.pl_g[n]) : 1.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = bq * 4 + r;
+                        if (m < M) {
+                            uint32_t hi, mid, lo;
+                            split3_pk(a.pl_g ? sum[r] * gn : sum[r], 0.0f, hi, mid, lo);
+                            a.pl_out[plane_elem(0, m, n)] = (bf16_t)hi;
+                            a.pl_out[plane_elem(1, m, n)] = (bf16_t)mid;
+                            a.pl_out[plane_elem(2, m, n)] = (bf16_t)lo;
+                        }
                     }
                 }
             }
@@ -1397,6 +1495,178 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
         }
     }
     ZG_STAMP_FLUSH();
+}
+
+// ================================================================================================
+// Plane-fed Linear of the lock-step batch, FOUR-WAVE workgroups (the per-layer Linears whose input rows arrive as
+// planes, GemvArgs.pl_in): one 16-row tile per workgroup, the four waves split the 64-k pairs of the (slice of) K.
+//
+// In-kernel timeline of the 16-wave kernel above at 124M x 8 (tools/kernel_stamps.py, ticks of ~0.45 ns): of a
+// 8.6-9.9 k tick body, 1.3-1.6 k are spent by wave 0 at the exchange barrier waiting for the last-launched of the 16
+// waves, and 2.0-3.3 k in the epilogue that wave 0 runs alone for all 128 outputs of the tile (some 450 VALU
+// instructions at 4 cycles each) — with the planes coming from global memory nothing is left that 16 waves would
+// share.  Here every lane issues all its loads at entry (weights as full 128-byte lines through a wave-private
+// transposing LDS slot, A fragments of its own pairs, its epilogue operands, its share of x for the LayerNorm
+// statistics), the waves meet once, and each wave finishes ONE accumulator register of the tile: lane (n = lane & 15,
+// half = lane >> 4 < 2) of wave w owns output (m = 4 half + w, n).  K slices over blockIdx.y (KSL > 1) combine per
+// wave: wave w of every slice publishes its 32 outputs, takes a ticket on counter [tile][w], and the last arriver adds
+// the slices in fixed order — no workgroup barrier on that path either.
+// KP = 64-k pairs per wave (K <= 256 KP per slice).
+// ================================================================================================
+template <int KP, int KSL>
+__global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict__ W, int N, int K, int M, int prologue,
+                                                       int epilogue, const GemvArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_stat[16];           // [8 rows][sum, sum of squares]
+    __shared__ __attribute__((aligned(16))) float s_part[4 * 32 * 4];   // [wave][lane < 32][4]
+    __shared__ __attribute__((aligned(16))) char s_slot[4 * 2048];      // transposing slot per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int ldw = K * KSL, npairs = K >> 6, nq = K >> 2;
+    if constexpr (KSL > 1) W += (size_t)blockIdx.y * K;
+    const int brow = lane & 15, bq = lane >> 4, lrow = lane >> 3, lpc = lane & 7;
+
+    // ---- every load of the kernel, issued up front
+    u32x4 wq[2 * KP];
+    {
+        const int r0 = tile * 16 + lrow;
+        const bf16_t* p0 = W + (size_t)min(r0, N - 1) * ldw + lpc * 8;
+        const bf16_t* p1 = W + (size_t)min(r0 + 8, N - 1) * ldw + lpc * 8;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const int qc = min(wave + 4 * i, npairs - 1);  // surplus pairs re-read the last one (weight 0 below)
+            wq[2 * i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p0 + qc * 64));
+            wq[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p1 + qc * 64));
+        }
+    }
+    u32x4 af[6 * KP];  // [pair][step of the pair][plane]; tile rows 8..15 have no batch row behind them: zeros
+    {
+        const bf16_t* pin = a.pl_in + (KSL > 1 ? (size_t)blockIdx.y * (K >> 5) * kPlaneStep : (size_t)0) + (lane & 7) * 32 + bq * 8;
+#pragma unroll
+        for (int i = 0; i < 2 * KP; ++i) {
+            const int st = 2 * min(wave + 4 * (i >> 1), npairs - 1) + (i & 1);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[i * 3 + p] = u32x4{0u, 0u, 0u, 0u};
+                if ((lane & 8) == 0) af[i * 3 + p] = *reinterpret_cast<const u32x4*>(pin + (size_t)(st * 3 + p) * 256);
+            }
+        }
+    }
+    const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    pf_count(a.progress);
+    const bool ln = prologue == PRO_LAYERNORM;
+    const int n = tile * 16 + brow, nc = min(n, N - 1);
+    const int m_out = (bq & 1) * 4 + wave, mc = min(m_out, M - 1);
+    float e_bias = 0.0f, e_c2 = 0.0f, e_res = 0.0f, e_g = 1.0f;
+    if (ln) {
+        e_c2 = a.ln_c2[nc];
+        e_bias = a.ln_c3[nc];  // c3 already holds the bias
+    } else if (a.bias) {
+        e_bias = a.bias[nc];
+    }
+    if (epilogue == EPI_RESIDUAL) e_res = a.resid[(size_t)mc * a.resid_stride + nc];
+    if (a.pl_out && a.pl_g) e_g = a.pl_g[nc];
+    f32x4 xv[2][KP];  // LayerNorm statistics: this wave sums rows wave and wave + 4
+    if (ln) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < KP; ++t)
+                xv[j][t] = reinterpret_cast<const f32x4*>(a.x + (size_t)min(wave + 4 * j, M - 1) * a.x_stride)[min(lane + 64 * t, nq - 1)];
+    }
+
+    // ---- MFMAs: weights -> B fragments through the slot (row rho x 8 pieces of 16 B, piece p at p ^ ((rho >> 1) & 7))
+    char* lslot = s_slot + wave * 2048;
+    const int wr0 = lrow * 128 + ((lpc ^ ((lrow >> 1) & 7)) << 4);
+    const int wr1 = (lrow + 8) * 128 + ((lpc ^ (((lrow + 8) >> 1) & 7)) << 4);
+    const int rd0 = brow * 128 + ((bq ^ ((brow >> 1) & 7)) << 4);        // step 2 q:     k = 64 q + 8 bq
+    const int rd1 = brow * 128 + (((4 + bq) ^ ((brow >> 1) & 7)) << 4);  // step 2 q + 1: k = 64 q + 32 + 8 bq
+    mf_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        *reinterpret_cast<u32x4*>(lslot + wr0) = wq[2 * i];
+        *reinterpret_cast<u32x4*>(lslot + wr1) = wq[2 * i + 1];
+        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
+        u32x4 v0 = *reinterpret_cast<const u32x4*>(lslot + rd0);
+        u32x4 v1 = *reinterpret_cast<const u32x4*>(lslot + rd1);
+        __builtin_amdgcn_wave_barrier();
+        if (wave + 4 * i >= npairs) v0 = v1 = u32x4{0u, 0u, 0u, 0u};
+        const mf_bf16x8 b0 = __builtin_bit_cast(mf_bf16x8, v0), b1 = __builtin_bit_cast(mf_bf16x8, v1);
+#pragma unroll
+        for (int p = 2; p >= 0; --p) {  // smallest plane first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, af[(2 * i) * 3 + p]), b0, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, af[(2 * i + 1) * 3 + p]), b1, acc1, 0, 0, 0);
+        }
+    }
+    if (ln) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = wave + 4 * j;
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < KP; ++t) {
+                f32x4 v = xv[j][t];
+                if (lane + 64 * t >= nq || m >= M) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                t1 += (v.x + v.y) + (v.z + v.w);
+                t2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, t2))));
+            }
+            t1 = wave_allsum(t1);
+            t2 = wave_allsum(t2);
+            if (lane == 0) {
+                s_stat[m * 2] = t1;
+                s_stat[m * 2 + 1] = t2;
+            }
+        }
+    }
+    acc += acc1;
+    if (lane < 32) *reinterpret_cast<mf_f32x4*>(s_part + (wave * 32 + lane) * 4) = acc;
+    __syncthreads();
+
+    // ---- this wave's register of the tile: output (m_out, n) in lanes 0..31
+    float y = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) y += s_part[(w * 32 + (lane & 31)) * 4 + wave];
+    bool run = true;
+    if constexpr (KSL > 1) {
+        // Publish with write-through (agent-scope relaxed atomic = sc1) stores, drain them, take a ticket; the last arriver
+        // reads all slices back with agent-scope loads.  No release / acquire fences (see gemv_mfma_kernel).
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        gu32* slot = (gu32*)(a.sk_ws + ((size_t)tile * KSL + blockIdx.y) * 128) + wave * 32 + (lane & 31);
+        if (lane < 32) __hip_atomic_store(slot, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.sk_cnt + tile * 4 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        run = ticket == KSL - 1;
+        if (run) {
+            const gu32* base = (const gu32*)(a.sk_ws + (size_t)tile * KSL * 128) + wave * 32 + (lane & 31);
+            unsigned bits[KSL];
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks) bits[ks] = __hip_atomic_load(base + ks * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            y = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks) y += __uint_as_float(bits[ks]);
+            if (lane == 0) __hip_atomic_store(a.sk_cnt + tile * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        }
+    }
+    if (run && lane < 32 && n < N && m_out < M) {
+        if (ln) {  // y = r_m (S1 - mu_m c2_n) + c3_n
+            const float inv_k = 1.0f / (float)K;
+            const float mu = s_stat[m_out * 2] * inv_k;
+            const float rs = __builtin_amdgcn_rsqf(s_stat[m_out * 2 + 1] * inv_k - mu * mu + a.eps);
+            y = fmaf(rs, fmaf(-mu, e_c2, y), e_bias);
+            e_bias = 0.0f;
+        }
+        Best nobest;
+        const float out = epilogue_row(a, m_out, n, y, e_bias, e_res, T - 1, nobest);
+        if (a.pl_out) {  // the next Linear reads this row as planes (of g * y when a LayerNorm follows)
+            uint32_t hi, mid, lo;
+            split3_pk(a.pl_g ? out * e_g : out, 0.0f, hi, mid, lo);
+            a.pl_out[plane_elem(0, m_out, n)] = (bf16_t)hi;
+            a.pl_out[plane_elem(1, m_out, n)] = (bf16_t)mid;
+            a.pl_out[plane_elem(2, m_out, n)] = (bf16_t)lo;
+        }
+    }
 }
 
 // ================================================================================================
@@ -1597,14 +1867,14 @@ int launch_lm_wpt(const GemvArgs& a, int grid, hipStream_t s) {
 
 inline int gemv_mfma_waves(const GemvArgs& a) { return a.epilogue == EPI_ARGMAX ? 4 : 16; }
 
-inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false, bool line = false) {
-    const size_t planes = (size_t)3 * kMfmaRows * (2 * K + 16);
+inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false, bool line = false, bool gpl = false) {
+    const size_t planes = gpl ? 0 : (size_t)3 * kMfmaRows * (2 * K + 16);
     return planes + 64 * sizeof(float) + (alias_partial ? 0 : (size_t)2 * nw * 64 * 4 * sizeof(float)) + (line ? (size_t)nw * 2048 : 0);
 }
 // full-line weight loads (LINE instantiations): whole pairs of 32-k steps and room for one 2-KiB slot per wave
-inline bool gemv_mfma_line(int K, int nw, bool alias_partial) {
+inline bool gemv_mfma_line(int K, int nw, bool alias_partial, bool gpl = false) {
     const int off = getenv("ZGPT2_NO_LINE_LOADS") ? atoi(getenv("ZGPT2_NO_LINE_LOADS")) : 0;  // read per call: tests flip it between handles
-    return !off && !alias_partial && K % 64 == 0 && gemv_mfma_lds(K, nw, false, true) <= 160 * 1024;
+    return !off && !alias_partial && K % 64 == 0 && gemv_mfma_lds(K, nw, false, true, gpl) <= 160 * 1024;
 }
 
 // single-tile workgroups may let the partial tiles alias the planes (see the kernel)
@@ -1612,18 +1882,18 @@ inline bool gemv_mfma_alias(const GemvArgs& a) {
     return a.kslices <= 1 && a.epilogue != EPI_ARGMAX && a.rows_per_wave == 1 && gemv_mfma_lds(a.K, 16) > 160 * 1024;
 }
 
-template <int KS, int NW, bool ARGMAX, int KSL, bool LINE>
+template <int KS, int NW, bool ARGMAX, int KSL, bool LINE, bool GPL = false>
 int launch_mfma_inst2(const GemvArgs& a, int grid, bool alias, hipStream_t s) {
-    const size_t lds = gemv_mfma_lds(a.K / KSL, NW, alias, LINE);
+    const size_t lds = gemv_mfma_lds(a.K / KSL, NW, alias, LINE, GPL);
     GemvArgs b = a;
     b.waves_per_wg = alias ? -1 : NW;  // < 0: partial tiles alias the planes
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE, GPL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE>), dim3(grid, KSL), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE, GPL>), dim3(grid, KSL), dim3(NW * 64), lds, s,
                        reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K / KSL, a.M, a.rows_per_wave, a.prologue,
                        a.epilogue, a.ln_g, a.ln_b, b);
     ZG_HIP(hipGetLastError());
@@ -1632,12 +1902,49 @@ int launch_mfma_inst2(const GemvArgs& a, int grid, bool alias, hipStream_t s) {
 
 template <int KS, int NW, bool ARGMAX, int KSL = 1>
 int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
+    if constexpr (!ARGMAX && NW == 16) {
+        if (a.pl_in) {  // input planes in global memory: no LDS planes, nothing to alias
+            if (gemv_mfma_line(a.K / KSL, NW, false, true)) return launch_mfma_inst2<KS, NW, ARGMAX, KSL, true, true>(a, grid, false, s);
+            return launch_mfma_inst2<KS, NW, ARGMAX, KSL, false, true>(a, grid, false, s);
+        }
+    }
     const bool alias = KSL == 1 && gemv_mfma_alias(a);
     if (gemv_mfma_line(a.K / KSL, NW, alias)) return launch_mfma_inst2<KS, NW, ARGMAX, KSL, true>(a, grid, alias, s);
     return launch_mfma_inst2<KS, NW, ARGMAX, KSL, false>(a, grid, alias, s);
 }
 
+// Plane-fed Linears as four-wave workgroups (gemv_pl4_kernel): one tile per workgroup, whole 64-k pairs, at most five
+// pairs per wave and slice (K <= 1280 per slice: every GPT-2 size but XL, which stays on the 16-wave kernel).
+inline int pl4_pairs(const GemvArgs& a) {
+    static const int off = getenv("ZGPT2_NO_PL4") ? atoi(getenv("ZGPT2_NO_PL4")) : 0;
+    if (off || a.pl_in == nullptr || a.epilogue == EPI_ARGMAX || a.rows_per_wave != 1) return 0;
+    const int ksl = a.kslices > 1 ? a.kslices : 1;
+    if (a.K % (64 * ksl) != 0) return 0;
+    const int kp = (a.K / ksl / 64 + 3) / 4;
+    return kp <= 5 ? kp : 0;
+}
+
+template <int KP>
+int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
+    if (a.kslices == 4)
+        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.W), a.N, a.K / 4, a.M,
+                           a.prologue, a.epilogue, a);
+    else
+        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.W), a.N, a.K, a.M, a.prologue,
+                           a.epilogue, a);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int launch_gemv_mfma(const GemvArgs& a, int grid, hipStream_t s) {
+    switch (pl4_pairs(a)) {
+        case 1: return launch_pl4<1>(a, grid, s);
+        case 2: return launch_pl4<2>(a, grid, s);
+        case 3: return launch_pl4<3>(a, grid, s);
+        case 4: return launch_pl4<4>(a, grid, s);
+        case 5: return launch_pl4<5>(a, grid, s);
+        default: break;
+    }
     if (a.kslices == 4) {  // four K slices over four workgroups per tile (gemv_kslices)
         const int ks = (a.K / 4 / 32 + 15) / 16;
         if (ks <= 2) return launch_mfma_inst<2, 16, false, 4>(a, grid, s);
@@ -1844,7 +2151,16 @@ int gemv_rows_per_wg(const GemvArgs& a, int weight_type) {
     return a.waves_per_wg * a.rows_per_wave;
 }
 
+bool gemv_planes_ok(const GemvArgs& a, int weight_type) {
+    if (a.epilogue == EPI_ARGMAX || !gemv_use_mfma(a, weight_type)) return false;
+    return a.prologue == PRO_NONE || (a.prologue == PRO_LAYERNORM && a.ln_c2 != nullptr && a.ln_c3 != nullptr && a.K <= 2048);
+}
+
+bool gemv_planes_producer_ok(const GemvArgs& a, int weight_type) { return a.epilogue != EPI_ARGMAX && gemv_use_mfma(a, weight_type); }
+
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
+    ZG_REQUIRE(a.pl_in == nullptr || gemv_planes_ok(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: input planes given to a launch outside the matrix-core path");
+    ZG_REQUIRE(a.pl_out == nullptr || gemv_use_mfma(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: output planes asked of a launch outside the matrix-core path");
     if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);
     if (gemv_use_ksplit(a)) return weight_type == WT_BF16 ? launch_ksplit<bf16_t>(a, s) : launch_ksplit<float>(a, s);
     if (gemv_use_lnk(a)) return weight_type == WT_BF16 ? launch_lnk<bf16_t>(a, s) : launch_lnk<float>(a, s);

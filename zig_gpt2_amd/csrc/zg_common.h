@@ -67,6 +67,14 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& hi, uint
     lo = cvt_pk_bf16(r0 - bf16_lo(mid), r1 - bf16_hi(mid));
 }
 
+// Activation planes of the lock-step batch in global memory: the epilogue of the producing kernel writes the exact
+// three-term bf16 split of its output row, the consuming Linear loads them as MFMA A fragments — no LDS staging and no
+// split in front of its MFMAs.  Element (plane p, batch row m < 8, column k) of a [3][8][K] triple sits at
+//   (((k >> 5) * 3 + p) * 8 + m) * 32 + (k & 31)    bf16 elements,
+// i.e. the three planes of the 8 rows of one 32-k MFMA step are 1536 contiguous bytes; a triple takes 48 K bytes.
+constexpr int kPlaneStep = 3 * 8 * 32;  // elements per 32-k step
+__host__ __device__ inline size_t plane_elem(int p, int m, int k) { return ((size_t)((k >> 5) * 3 + p) * 8 + m) * 32 + (k & 31); }
+
 // DPP row rotate inside each 16-lane row: every lane reads the lane `n` to its right (cyclic).
 template <int N>
 __device__ __forceinline__ float dpp_row_ror(float v) {

@@ -60,12 +60,21 @@ struct GemvArgs {
     int logits_stride;
     float* part_val;
     int* part_idx;
-    // split-K over workgroups (batched wide Linears): combine workspace [sk_tiles][4][128] floats and one counter per
-    // tile (zero between launches: the last arriver resets its tile's counter); kslices is filled by gemv_plan
+    // split-K over workgroups (batched wide Linears): combine workspace [sk_tiles][4][128] floats and FOUR counters per
+    // tile (zero between launches: the last arriver resets its counter; the 16-wave kernel uses counter [tile], the
+    // four-wave plane-fed kernel one per wave, [4 tile + wave]); kslices is filled by gemv_plan
     float* sk_ws;
     int* sk_cnt;
     int sk_tiles;
     int kslices;
+    // lock-step batch on the matrix cores: activation planes in global memory (zg_common.h plane_elem).  pl_in: the
+    // input rows arrive as planes written by the previous kernel (PRO_LAYERNORM: planes of g * x, x itself is read for
+    // the row statistics only; PRO_NONE: planes of x).  pl_out: this kernel's output rows (after residual / GELU) are
+    // also written as planes, scaled by pl_g[n] when given (the next LayerNorm's gain); EPI_GELU with y == nullptr
+    // writes only the planes.
+    const bf16_t* pl_in;
+    bf16_t* pl_out;
+    const float* pl_g;
     const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
     unsigned* progress;       // launch counter followed by the side-stream prefetcher (prefetch.hip); null = not counted
@@ -73,6 +82,10 @@ struct GemvArgs {
 
 // Whether launch_gemv can run this M x K at all (batched kernels keep the M input rows in LDS).
 bool gemv_supported(const GemvArgs& a, int weight_type);
+// Whether this launch may take its input rows as planes in global memory (GemvArgs.pl_in).
+bool gemv_planes_ok(const GemvArgs& a, int weight_type);
+// ... and whether it can write its output rows as planes (GemvArgs.pl_out).
+bool gemv_planes_producer_ok(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int gemv_kslices(const GemvArgs& a);
@@ -194,6 +207,8 @@ struct EmbedArgs {
     int part_stride;
     int n_partials;          // lm_head grid size
     float* x;                // [B][E]
+    bf16_t* pl_out;          // optional planes of pl_g * x for the first Linear of the lock-step batch (GemvArgs.pl_in)
+    const float* pl_g;
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
     unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
 };
