@@ -58,7 +58,10 @@ struct zg_gpt {
     bf16_t *pf_a, *pf_h;
     // lock-step batch with bf16 weights: activation planes between the kernels of a Block (GemvArgs.pl_in / pl_out):
     // xp = planes of g * x for the next LayerNorm-fed Linear [48 E bytes], hp = planes of gelu(c_fc) [48 * 4E bytes]
-    bf16_t *xp, *hp;
+    // ap = planes of the merged attention output [48 E bytes], written by the last split of every (sequence, head)
+    // (AttnArgs.pl_out; attn_cnt = its arrival counters)
+    bf16_t *xp, *hp, *ap;
+    int* attn_cnt;
     bool pl_on;
     int max_splits, lm_grid;
     // pinned host mirrors for small control traffic
@@ -161,6 +164,8 @@ void carve(zg_gpt* g, char* base) {
     g->out_tokens = (int*)P(B * C * 4);
     g->xp = (bf16_t*)P(E * 48);
     g->hp = (bf16_t*)P(4 * E * 48);
+    g->ap = (bf16_t*)P(E * 48);
+    g->attn_cnt = (int*)P(8 * c.n_heads * 4);
     g->sk_tiles = (int)((E + 15) / 16);
     g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
     g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4 * 4);  // [tile][4]: the four-wave plane-fed kernel takes one ticket per wave
@@ -371,6 +376,10 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.max_splits = g->max_splits;
             a.part = g->part;
             a.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
+            if (g->pl_on) {
+                a.pl_out = g->ap;
+                a.merge_cnt = g->attn_cnt;
+            }
             if (rec) {  // the K and V rows of earlier positions, laid out for this grid
                 PfJob j{};
                 j.kind = PF_KV;
@@ -395,7 +404,9 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y_stride = (int)E;
             a.resid = g->x;
             a.resid_stride = (int)E;
-            if (g->pl_on) {
+            if (g->pl_on) {  // the heads arrive merged, as planes
+                a.prologue = PRO_NONE;
+                a.pl_in = g->ap;
                 a.pl_out = g->xp;
                 a.pl_g = y.ln_2_g;
             }
@@ -799,10 +810,10 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         a5.prologue = PRO_NONE;
         a5.epilogue = EPI_RESIDUAL;
         GemvArgs a3 = base_gemv(g, y.c_proj_w, y.c_proj_b, c.n_embed, c.n_embed, 0);
-        a3.prologue = PRO_ATTN_MERGE;
+        a3.prologue = PRO_NONE;
         a3.epilogue = EPI_RESIDUAL;
-        g->pl_on = c.n_embed % 32 == 0 && gemv_planes_ok(a1, g->wt) && gemv_planes_ok(a4, g->wt) && gemv_planes_ok(a5, g->wt) &&
-                   gemv_supported(a3, g->wt) && gemv_planes_producer_ok(a3, g->wt);
+        g->pl_on = c.n_embed % 32 == 0 && gemv_planes_ok(a1, g->wt) && gemv_planes_ok(a3, g->wt) && gemv_planes_ok(a4, g->wt) &&
+                   gemv_planes_ok(a5, g->wt);
     }
     if (g->lm_grid > 4096) {
         (void)hipFree(g->arena);

@@ -89,6 +89,85 @@ __device__ __forceinline__ float row16_reduce_scatter(float (&s)[16], int lr) {
     }
 }
 
+// Wave 0 of a split hands over its partial (o[lane], M, l).  Op tier / one sequence: plain stores, the consumer merges
+// (attn_merge_kernel, or the c_proj prologue).  Lock-step batch with activation planes (AttnArgs.pl_out): the LAST split
+// of (b, h) to arrive merges all of them — same arithmetic as merge_attn4 in gemv.hip: weights exp(m_s - max m), sums
+// in split order, one reciprocal — and writes the head's 64 outputs as the three bf16 planes the c_proj Linear loads as
+// MFMA A fragments (zg_common.h plane_elem).  Publish with write-through (agent-scope relaxed atomic) stores, drain
+// them, take a ticket, read back with agent-scope loads: the fence-free pattern of the split-K Linears (gemv.hip).
+__device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h, int split, int lane, float o, float M, float l) {
+    float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
+    if (a.pl_out == nullptr) {
+        part[lane] = o;
+        if (lane == 0) {
+            part[64] = M;
+            part[65] = l;
+        }
+        return;
+    }
+    const int nsplit = (int)gridDim.y;  // every launched split publishes (those beyond seq_len with weight 0)
+    float r = o, lsum = l;
+    if (nsplit > 1) {
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        gu32* gp = (gu32*)part;
+        __hip_atomic_store(gp + lane, __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(gp + 64, __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gp + 65, __float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* cnt = a.merge_cnt + b * a.n_heads + h;
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != nsplit - 1) return;
+        if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        const gu32* p0 = (const gu32*)(a.part + ((size_t)b * a.n_heads + h) * a.max_splits * kPartStride);
+        constexpr int MAXS = 4;  // ctx 1024 / 256; more splits take the loop below
+        if (nsplit <= MAXS) {
+            float ms[MAXS], ls[MAXS], os[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {  // branch-free: surplus splits re-read the last valid one ...
+                const gu32* ps = p0 + min(s, nsplit - 1) * kPartStride;
+                ms[s] = __uint_as_float(__hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                ls[s] = __uint_as_float(__hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                os[s] = __uint_as_float(__hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (s >= nsplit) ms[s] = -1e30f;  // ... and get weight exp(-1e30 - max) == 0
+            const float mx = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
+            r = 0.0f;
+            lsum = 0.0f;
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                const float w = __expf(ms[s] - mx);
+                lsum = fmaf(w, ls[s], lsum);
+                r = fmaf(w, os[s], r);
+            }
+        } else {
+            float mx = -1e30f;
+            for (int s = 0; s < nsplit; ++s)
+                mx = fmaxf(mx, __uint_as_float(__hip_atomic_load(p0 + s * kPartStride + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            r = 0.0f;
+            lsum = 0.0f;
+            for (int s = 0; s < nsplit; ++s) {
+                const gu32* ps = p0 + s * kPartStride;
+                const float w = __expf(__uint_as_float(__hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - mx);
+                lsum = fmaf(w, __uint_as_float(__hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), lsum);
+                r = fmaf(w, __uint_as_float(__hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), r);
+            }
+        }
+    }
+    const float v = r * (1.0f / lsum);
+    uint32_t hi, mid, lo;
+    split3_pk(v, 0.0f, hi, mid, lo);
+    const int k = h * 64 + lane;
+    a.pl_out[plane_elem(0, b, k)] = (bf16_t)hi;
+    a.pl_out[plane_elem(1, b, k)] = (bf16_t)mid;
+    a.pl_out[plane_elem(2, b, k)] = (bf16_t)lo;
+}
+
 // grid (H, max_splits, B), block 256.  Requires head_dim == 64.
 template <typename KV>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
@@ -176,12 +255,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             o = fmaf(sc, s_o[w][lane], o);
             l = fmaf(sc, s_l[w], l);
         }
-        float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
-        part[lane] = o;
-        if (lane == 0) {
-            part[64] = M;
-            part[65] = l;
-        }
+        publish_partial(a, b, h, split, lane, o, M, l);
     }
 }
 
@@ -313,12 +387,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
             ov = fmaf(sc, s_o[w][lane], ov);
             l = fmaf(sc, s_l[w], l);
         }
-        float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
-        part[lane] = ov;
-        if (lane == 0) {
-            part[64] = M;
-            part[65] = l;
-        }
+        publish_partial(a, b, h, split, lane, ov, M, l);
     }
 }
 

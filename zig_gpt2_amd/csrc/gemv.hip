@@ -1513,16 +1513,29 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // the slices in fixed order — no workgroup barrier on that path either.
 // KP = 64-k pairs per wave (K <= 256 KP per slice).
 // ================================================================================================
+// Arguments: everything an address of the up-front loads depends on sits in the first 16 dwords, which the hardware
+// preloads into SGPRs at wave launch (-amdgpu-kernarg-preload-count=16); fields of the GemvArgs block behind them cost a
+// scalar load from the kernarg segment first, ~2 k ticks on a cold launch (the first version took W alone as a leading
+// argument and spent 3.4 k of its 7.4 k ticks before the last load was issued).  nk = N | K << 16 (K = slice width),
+// flags = M | prologue << 4 | epilogue << 8, e0 / e1 / e2 = the epilogue's per-column operands: (c2, c3, -) behind a
+// folded LayerNorm, (bias, residual, gain of the planes written) otherwise; x rows are K apart, residual rows N apart.
 template <int KP, int KSL>
-__global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict__ W, int N, int K, int M, int prologue,
-                                                       int epilogue, const GemvArgs a) {
+__global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ pl_in,
+                                                       const float* __restrict__ x, unsigned nk, unsigned flags,
+                                                       const float* __restrict__ e0, const float* __restrict__ e1,
+                                                       const float* __restrict__ e2, const StepCtrl* __restrict__ ctrl,
+                                                       const GemvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_stat[16];           // [8 rows][sum, sum of squares]
     __shared__ __attribute__((aligned(16))) float s_part[4 * 32 * 4];   // [wave][lane < 32][4]
-    __shared__ __attribute__((aligned(16))) char s_slot[4 * 2048];      // transposing slot per wave
+    __shared__ __attribute__((aligned(16))) char s_slot[4 * KP * 2048];  // transposing slots: one per wave and pair
+    const int N = (int)(nk & 0xffffu), K = (int)(nk >> 16);
+    const int M = (int)(flags & 15u), prologue = (int)((flags >> 4) & 15u), epilogue = (int)((flags >> 8) & 15u);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
     const int ldw = K * KSL, npairs = K >> 6, nq = K >> 2;
+    ZG_STAMP_DECL();
+    ZG_STAMP(0);
     if constexpr (KSL > 1) W += (size_t)blockIdx.y * K;
     const int brow = lane & 15, bq = lane >> 4, lrow = lane >> 3, lpc = lane & 7;
 
@@ -1541,7 +1554,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     }
     u32x4 af[6 * KP];  // [pair][step of the pair][plane]; tile rows 8..15 have no batch row behind them: zeros
     {
-        const bf16_t* pin = a.pl_in + (KSL > 1 ? (size_t)blockIdx.y * (K >> 5) * kPlaneStep : (size_t)0) + (lane & 7) * 32 + bq * 8;
+        const bf16_t* pin = pl_in + (KSL > 1 ? (size_t)blockIdx.y * (K >> 5) * kPlaneStep : (size_t)0) + (lane & 7) * 32 + bq * 8;
 #pragma unroll
         for (int i = 0; i < 2 * KP; ++i) {
             const int st = 2 * min(wave + 4 * (i >> 1), npairs - 1) + (i & 1);
@@ -1552,31 +1565,32 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             }
         }
     }
-    const int T = a.ctrl ? a.ctrl->seq_len : 1;
-    pf_count(a.progress);
+    const int T = ctrl ? ctrl->seq_len : 1;
     const bool ln = prologue == PRO_LAYERNORM;
     const int n = tile * 16 + brow, nc = min(n, N - 1);
     const int m_out = (bq & 1) * 4 + wave, mc = min(m_out, M - 1);
     float e_bias = 0.0f, e_c2 = 0.0f, e_res = 0.0f, e_g = 1.0f;
     if (ln) {
-        e_c2 = a.ln_c2[nc];
-        e_bias = a.ln_c3[nc];  // c3 already holds the bias
-    } else if (a.bias) {
-        e_bias = a.bias[nc];
+        e_c2 = e0[nc];
+        e_bias = e1[nc];  // c3 already holds the bias
+    } else {
+        if (e0) e_bias = e0[nc];
+        if (e1) e_res = e1[(size_t)mc * N + nc];
+        if (e2) e_g = e2[nc];
     }
-    if (epilogue == EPI_RESIDUAL) e_res = a.resid[(size_t)mc * a.resid_stride + nc];
-    if (a.pl_out && a.pl_g) e_g = a.pl_g[nc];
     f32x4 xv[2][KP];  // LayerNorm statistics: this wave sums rows wave and wave + 4
     if (ln) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int t = 0; t < KP; ++t)
-                xv[j][t] = reinterpret_cast<const f32x4*>(a.x + (size_t)min(wave + 4 * j, M - 1) * a.x_stride)[min(lane + 64 * t, nq - 1)];
+                xv[j][t] = reinterpret_cast<const f32x4*>(x + (size_t)min(wave + 4 * j, M - 1) * K)[min(lane + 64 * t, nq - 1)];
     }
 
+    ZG_STAMP(1);
     // ---- MFMAs: weights -> B fragments through the slot (row rho x 8 pieces of 16 B, piece p at p ^ ((rho >> 1) & 7))
-    char* lslot = s_slot + wave * 2048;
+    // (one slot per pair: all writes, then all reads, then the MFMAs — the LDS round trips of the pairs overlap)
+    char* lslot = s_slot + wave * (KP * 2048);
     const int wr0 = lrow * 128 + ((lpc ^ ((lrow >> 1) & 7)) << 4);
     const int wr1 = (lrow + 8) * 128 + ((lpc ^ (((lrow + 8) >> 1) & 7)) << 4);
     const int rd0 = brow * 128 + ((bq ^ ((brow >> 1) & 7)) << 4);        // step 2 q:     k = 64 q + 8 bq
@@ -1584,20 +1598,27 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     mf_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
-        *reinterpret_cast<u32x4*>(lslot + wr0) = wq[2 * i];
-        *reinterpret_cast<u32x4*>(lslot + wr1) = wq[2 * i + 1];
-        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
-        u32x4 v0 = *reinterpret_cast<const u32x4*>(lslot + rd0);
-        u32x4 v1 = *reinterpret_cast<const u32x4*>(lslot + rd1);
-        __builtin_amdgcn_wave_barrier();
-        if (wave + 4 * i >= npairs) v0 = v1 = u32x4{0u, 0u, 0u, 0u};
-        const mf_bf16x8 b0 = __builtin_bit_cast(mf_bf16x8, v0), b1 = __builtin_bit_cast(mf_bf16x8, v1);
+        *reinterpret_cast<u32x4*>(lslot + i * 2048 + wr0) = wq[2 * i];
+        *reinterpret_cast<u32x4*>(lslot + i * 2048 + wr1) = wq[2 * i + 1];
+    }
+    __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
+    u32x4 bv[2 * KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        bv[2 * i] = *reinterpret_cast<const u32x4*>(lslot + i * 2048 + rd0);
+        bv[2 * i + 1] = *reinterpret_cast<const u32x4*>(lslot + i * 2048 + rd1);
+        if (wave + 4 * i >= npairs) bv[2 * i] = bv[2 * i + 1] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const mf_bf16x8 b0 = __builtin_bit_cast(mf_bf16x8, bv[2 * i]), b1 = __builtin_bit_cast(mf_bf16x8, bv[2 * i + 1]);
 #pragma unroll
         for (int p = 2; p >= 0; --p) {  // smallest plane first
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, af[(2 * i) * 3 + p]), b0, acc, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, af[(2 * i + 1) * 3 + p]), b1, acc1, 0, 0, 0);
         }
     }
+    ZG_STAMP(2);
     if (ln) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1619,8 +1640,11 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         }
     }
     acc += acc1;
+    ZG_STAMP(3);
     if (lane < 32) *reinterpret_cast<mf_f32x4*>(s_part + (wave * 32 + lane) * 4) = acc;
+    pf_count(a.progress);
     __syncthreads();
+    ZG_STAMP(4);
 
     // ---- this wave's register of the tile: output (m_out, n) in lanes 0..31
     float y = 0.0f;
@@ -1649,6 +1673,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             if (lane == 0) __hip_atomic_store(a.sk_cnt + tile * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
         }
     }
+    ZG_STAMP(5);
     if (run && lane < 32 && n < N && m_out < M) {
         if (ln) {  // y = r_m (S1 - mu_m c2_n) + c3_n
             const float inv_k = 1.0f / (float)K;
@@ -1661,12 +1686,15 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         const float out = epilogue_row(a, m_out, n, y, e_bias, e_res, T - 1, nobest);
         if (a.pl_out) {  // the next Linear reads this row as planes (of g * y when a LayerNorm follows)
             uint32_t hi, mid, lo;
-            split3_pk(a.pl_g ? out * e_g : out, 0.0f, hi, mid, lo);
+            split3_pk(e2 ? out * e_g : out, 0.0f, hi, mid, lo);
             a.pl_out[plane_elem(0, m_out, n)] = (bf16_t)hi;
             a.pl_out[plane_elem(1, m_out, n)] = (bf16_t)mid;
             a.pl_out[plane_elem(2, m_out, n)] = (bf16_t)lo;
         }
     }
+    ZG_STAMP(6);
+    ZG_STAMP(7);
+    ZG_STAMP_FLUSH();
 }
 
 // ================================================================================================
@@ -1918,6 +1946,7 @@ int launch_mfma_inst(const GemvArgs& a, int grid, hipStream_t s) {
 inline int pl4_pairs(const GemvArgs& a) {
     static const int off = getenv("ZGPT2_NO_PL4") ? atoi(getenv("ZGPT2_NO_PL4")) : 0;
     if (off || a.pl_in == nullptr || a.epilogue == EPI_ARGMAX || a.rows_per_wave != 1) return 0;
+    if (a.N > 0xffff || (a.prologue == PRO_LAYERNORM && a.x_stride != a.K) || (a.epilogue == EPI_RESIDUAL && a.resid_stride != a.N)) return 0;
     const int ksl = a.kslices > 1 ? a.kslices : 1;
     if (a.K % (64 * ksl) != 0) return 0;
     const int kp = (a.K / ksl / 64 + 3) / 4;
@@ -1926,12 +1955,16 @@ inline int pl4_pairs(const GemvArgs& a) {
 
 template <int KP>
 int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
-    if (a.kslices == 4)
-        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.W), a.N, a.K / 4, a.M,
-                           a.prologue, a.epilogue, a);
-    else
-        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.W), a.N, a.K, a.M, a.prologue,
-                           a.epilogue, a);
+    const bool ln = a.prologue == PRO_LAYERNORM;
+    const int ksl = a.kslices == 4 ? 4 : 1;
+    const unsigned nk = (unsigned)a.N | ((unsigned)(a.K / ksl) << 16);
+    const unsigned flags = (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8);
+    const float* e0 = ln ? a.ln_c2 : a.bias;
+    const float* e1 = ln ? a.ln_c3 : (a.epilogue == EPI_RESIDUAL ? a.resid : nullptr);
+    const float* e2 = (!ln && a.pl_out) ? a.pl_g : nullptr;
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+    if (ksl == 4) hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2, a.ctrl, a);
+    else hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2, a.ctrl, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

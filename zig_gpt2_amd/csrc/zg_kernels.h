@@ -109,6 +109,10 @@ struct AttnArgs {
     int max_splits;
     float* part;  // [B][H][max_splits][kPartStride]
     unsigned* progress;  // see GemvArgs
+    // lock-step batch with activation planes: the last split of (b, h) to arrive merges them and writes the head's output as
+    // planes [3][8][H * 64] (plane_elem) for the c_proj Linear; merge_cnt = one zeroed counter per (b, h)
+    bf16_t* pl_out;
+    int* merge_cnt;
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t s);
 // Standalone merge (op tier): out[b][h*hd+d] = sum_s w_s o_s / sum_s w_s l_s
