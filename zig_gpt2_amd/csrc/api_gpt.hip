@@ -62,6 +62,10 @@ struct zg_gpt {
     // (AttnArgs.pl_out; attn_cnt = its arrival counters)
     bf16_t *xp, *hp, *ap;
     int* attn_cnt;
+    // tagged hand-overs (GemvArgs.sk_tag, AttnArgs.part_tag): step counter advanced by the embed kernel, (value, tag) words
+    unsigned* epoch;
+    unsigned long long *sk_tag, *part_tag;
+    bool tags_on;
     bool pl_on;
     int max_splits, lm_grid;
     // pinned host mirrors for small control traffic
@@ -166,6 +170,9 @@ void carve(zg_gpt* g, char* base) {
     g->hp = (bf16_t*)P(4 * E * 48);
     g->ap = (bf16_t*)P(E * 48);
     g->attn_cnt = (int*)P(8 * c.n_heads * 4);
+    g->epoch = (unsigned*)P(256);
+    g->sk_tag = (unsigned long long*)P(((E + 15) / 16) * 4 * 128 * 8);
+    g->part_tag = (unsigned long long*)P(8 * c.n_heads * g->max_splits * kPartStride * 8);
     g->sk_tiles = (int)((E + 15) / 16);
     g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
     g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4 * 4);  // [tile][4]: the four-wave plane-fed kernel takes one ticket per wave
@@ -239,6 +246,7 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.x = g->x;
     e.pl_out = g->pl_on ? g->xp : nullptr;
     e.pl_g = g->layers[0].ln_1_g;
+    e.epoch = (g->pl_on && g->tags_on && finish_only != 1 && finish_only != 2) ? g->epoch : nullptr;
     e.finish_only = finish_only;
     e.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
     return e;
@@ -379,6 +387,11 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             if (g->pl_on) {
                 a.pl_out = g->ap;
                 a.merge_cnt = g->attn_cnt;
+                if (g->tags_on && 2 * l + 1 <= 255) {
+                    a.epoch = g->epoch;
+                    a.launch_id = (unsigned)(2 * l + 1);
+                    a.part_tag = g->part_tag;
+                }
             }
             if (rec) {  // the K and V rows of earlier positions, laid out for this grid
                 PfJob j{};
@@ -446,6 +459,11 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.resid = g->x;
             a.resid_stride = (int)E;
             if (g->pl_on) {
+                if (g->tags_on && 2 * l + 2 <= 255) {
+                    a.epoch = g->epoch;
+                    a.launch_id = (unsigned)(2 * l + 2);
+                    a.sk_tag = g->sk_tag;
+                }
                 a.pl_in = g->hp;
                 if (l + 1 < g->cfg.n_layer) {  // the next Block's ln_1 + c_attn (ln_f + lm_head reads x itself)
                     a.pl_out = g->xp;
@@ -815,6 +833,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         g->pl_on = c.n_embed % 32 == 0 && gemv_planes_ok(a1, g->wt) && gemv_planes_ok(a3, g->wt) && gemv_planes_ok(a4, g->wt) &&
                    gemv_planes_ok(a5, g->wt);
     }
+    g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
     if (g->lm_grid > 4096) {
         (void)hipFree(g->arena);
         delete g;

@@ -95,7 +95,8 @@ __device__ __forceinline__ float row16_reduce_scatter(float (&s)[16], int lr) {
 // in split order, one reciprocal — and writes the head's 64 outputs as the three bf16 planes the c_proj Linear loads as
 // MFMA A fragments (zg_common.h plane_elem).  Publish with write-through (agent-scope relaxed atomic) stores, drain
 // them, take a ticket, read back with agent-scope loads: the fence-free pattern of the split-K Linears (gemv.hip).
-__device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h, int split, int lane, float o, float M, float l) {
+__device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h, int split, int lane, float o, float M, float l,
+                                                unsigned tag) {
     float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
     if (a.pl_out == nullptr) {
         part[lane] = o;
@@ -107,7 +108,78 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
     }
     const int nsplit = (int)gridDim.y;  // every launched split publishes (those beyond seq_len with weight 0)
     float r = o, lsum = l;
-    if (nsplit > 1) {
+    if (nsplit > 1 && a.part_tag) {
+        // Tagged hand-over: splits 1.. store (value, tag) words and are done; split 0 polls them — one memory-side round
+        // trip behind the slowest split instead of the three of the ticket below (drain, ticket, read back).
+        typedef unsigned long long u64;
+        auto pack = [&](float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); };
+        u64* pt = a.part_tag + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
+        if (split != 0) {
+            __hip_atomic_store(pt + lane, pack(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                __hip_atomic_store(pt + 64, pack(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pt + 65, pack(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        float mx = M;
+        r = 0.0f;
+        lsum = 0.0f;
+        constexpr int MAXS = 4;
+        if (nsplit <= MAXS) {
+            u64 vo[MAXS - 1], vm[MAXS - 1], vl[MAXS - 1];
+            for (int spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int s = 1; s < MAXS; ++s) {  // surplus splits re-read the last valid one (weight 0 below)
+                    const u64* ps = pt + min(s, nsplit - 1) * kPartStride;
+                    vo[s - 1] = __hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vm[s - 1] = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vl[s - 1] = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(vo[s - 1] >> 32) == tag && (unsigned)(vm[s - 1] >> 32) == tag && (unsigned)(vl[s - 1] >> 32) == tag;
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0 || spins > (1 << 20)) break;  // bounded: never hang the queue
+                __builtin_amdgcn_s_sleep(1);
+            }
+            float ms[MAXS], ls[MAXS], os[MAXS];
+            ms[0] = M; ls[0] = l; os[0] = o;
+#pragma unroll
+            for (int s = 1; s < MAXS; ++s) {
+                ms[s] = s < nsplit ? __uint_as_float((unsigned)vm[s - 1]) : -1e30f;
+                ls[s] = __uint_as_float((unsigned)vl[s - 1]);
+                os[s] = __uint_as_float((unsigned)vo[s - 1]);
+            }
+            mx = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                const float w = __expf(ms[s] - mx);
+                lsum = fmaf(w, ls[s], lsum);
+                r = fmaf(w, os[s], r);
+            }
+        } else {  // long contexts: one split at a time, running maximum
+            float mrun = M;
+            r = o;
+            lsum = l;
+            for (int s = 1; s < nsplit; ++s) {
+                const u64* ps = pt + s * kPartStride;
+                u64 vo, vm, vl;
+                for (int spins = 0;; ++spins) {
+                    vo = __hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vm = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vl = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = (unsigned)(vo >> 32) == tag && (unsigned)(vm >> 32) == tag && (unsigned)(vl >> 32) == tag;
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0 || spins > (1 << 20)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const float m_s = __uint_as_float((unsigned)vm);
+                const float mnew = fmaxf(mrun, m_s);
+                const float w0 = __expf(mrun - mnew), w1 = __expf(m_s - mnew);
+                r = fmaf(w1, __uint_as_float((unsigned)vo), r * w0);
+                lsum = fmaf(w1, __uint_as_float((unsigned)vl), lsum * w0);
+                mrun = mnew;
+            }
+        }
+    } else if (nsplit > 1) {
         typedef __attribute__((address_space(1))) unsigned gu32;
         gu32* gp = (gu32*)part;
         __hip_atomic_store(gp + lane, __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -180,6 +252,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     // device control block; seq_len is needed for masking alone.
     const int t_hi = a.t_hi;
     const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
+    const unsigned tag = a.part_tag ? ((*a.epoch << 8) | a.launch_id) : 0u;  // tagged hand-over of the split partials
     const int chunk0 = split * kAttnChunk;
     if (chunk0 >= t_hi) return;  // nothing to attend to in this split (consumer skips it too)
 
@@ -255,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             o = fmaf(sc, s_o[w][lane], o);
             l = fmaf(sc, s_l[w], l);
         }
-        publish_partial(a, b, h, split, lane, o, M, l);
+        publish_partial(a, b, h, split, lane, o, M, l, tag);
     }
 }
 
@@ -306,6 +379,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
     const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
     const int t_hi = a.t_hi;
     const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
+    const unsigned tag = a.part_tag ? ((*a.epoch << 8) | a.launch_id) : 0u;  // tagged hand-over of the split partials
     const int chunk0 = split * kAttnChunk;
     if (chunk0 >= t_hi) return;
 
@@ -387,7 +461,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
             ov = fmaf(sc, s_o[w][lane], ov);
             l = fmaf(sc, s_l[w], l);
         }
-        publish_partial(a, b, h, split, lane, ov, M, l);
+        publish_partial(a, b, h, split, lane, ov, M, l, tag);
     }
 }
 

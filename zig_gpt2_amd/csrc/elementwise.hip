@@ -233,6 +233,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
             *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(2, b, e)) = u32x2{l0, l1};
         }
     }
+    if (threadIdx.x == 0 && a.epoch) *a.epoch += 1u;  // a step starts: new tags for its hand-overs
     if (threadIdx.x == 0 && a.finish_only == 0) {
         a.ctrl->seq_len = s + 1;
         a.ctrl->step = s + 1;

@@ -1523,7 +1523,7 @@ template <int KP, int KSL>
 __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ pl_in,
                                                        const float* __restrict__ x, unsigned nk, unsigned flags,
                                                        const float* __restrict__ e0, const float* __restrict__ e1,
-                                                       const float* __restrict__ e2, const StepCtrl* __restrict__ ctrl,
+                                                       const float* __restrict__ e2, const void* __restrict__ cp,
                                                        const GemvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_stat[16];           // [8 rows][sum, sum of squares]
     __shared__ __attribute__((aligned(16))) float s_part[4 * 32 * 4];   // [wave][lane < 32][4]
@@ -1565,7 +1565,9 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             }
         }
     }
-    const int T = ctrl ? ctrl->seq_len : 1;
+    // cp: the step control block (sequence length for the KV append), or, for K slices, the epoch word of the tags
+    const int T = (KSL == 1 && cp) ? static_cast<const StepCtrl*>(cp)->seq_len : 1;
+    const unsigned tag = (KSL > 1 && a.sk_tag) ? ((*static_cast<const unsigned*>(cp) << 8) | a.launch_id) : 0u;
     const bool ln = prologue == PRO_LAYERNORM;
     const int n = tile * 16 + brow, nc = min(n, N - 1);
     const int m_out = (bq & 1) * 4 + wave, mc = min(m_out, M - 1);
@@ -1651,7 +1653,30 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int w = 0; w < 4; ++w) y += s_part[(w * 32 + (lane & 31)) * 4 + wave];
     bool run = true;
-    if constexpr (KSL > 1) {
+    if (KSL > 1 && a.sk_tag) {
+        // Tagged hand-over: slices 1.. store (value, tag) words and are done; slice 0 polls them and adds in slice order —
+        // one memory-side round trip behind the slowest slice instead of the three of the ticket below.
+        typedef unsigned long long u64;
+        u64* slot = a.sk_tag + ((size_t)tile * KSL + blockIdx.y) * 128 + wave * 32 + (lane & 31);
+        if (blockIdx.y != 0) {
+            if (lane < 32) __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            run = false;
+        } else {
+            u64 v[KSL];
+            for (int spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int ks = 1; ks < KSL; ++ks) {
+                    v[ks] = __hip_atomic_load(slot + ks * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(v[ks] >> 32) == tag;
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0 || spins > (1 << 20)) break;  // bounded: never hang the queue
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int ks = 1; ks < KSL; ++ks) y += __uint_as_float((unsigned)v[ks]);
+        }
+    } else if constexpr (KSL > 1) {
         // Publish with write-through (agent-scope relaxed atomic = sc1) stores, drain them, take a ticket; the last arriver
         // reads all slices back with agent-scope loads.  No release / acquire fences (see gemv_mfma_kernel).
         typedef __attribute__((address_space(1))) unsigned gu32;
@@ -1963,8 +1988,15 @@ int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
     const float* e1 = ln ? a.ln_c3 : (a.epilogue == EPI_RESIDUAL ? a.resid : nullptr);
     const float* e2 = (!ln && a.pl_out) ? a.pl_g : nullptr;
     const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
-    if (ksl == 4) hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2, a.ctrl, a);
-    else hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2, a.ctrl, a);
+    if (ksl == 4) {
+        GemvArgs b = a;
+        if (b.epoch == nullptr || b.launch_id == 0 || b.launch_id > 255) b.sk_tag = nullptr;  // tickets
+        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2,
+                           static_cast<const void*>(b.sk_tag ? b.epoch : nullptr), b);
+    } else {
+        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2,
+                           static_cast<const void*>(a.ctrl), a);
+    }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

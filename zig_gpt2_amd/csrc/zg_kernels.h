@@ -75,6 +75,13 @@ struct GemvArgs {
     const bf16_t* pl_in;
     bf16_t* pl_out;
     const float* pl_g;
+    // K slices of the four-wave plane-fed kernel meet by TAGGED DATA instead of tickets: slices 1.. store (value, tag) as one
+    // 8-byte word, slice 0 polls until the tags are this launch's — one memory-side round trip instead of three.
+    // tag = *epoch << 8 | launch_id: epoch is advanced by the embed kernel at every step, launch_id (1..255) is unique
+    // among the launches of a step that share sk_tag [sk_tiles][4][128].
+    const unsigned* epoch;
+    unsigned launch_id;
+    unsigned long long* sk_tag;
     const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
     unsigned* progress;       // launch counter followed by the side-stream prefetcher (prefetch.hip); null = not counted
@@ -113,6 +120,11 @@ struct AttnArgs {
     // planes [3][8][H * 64] (plane_elem) for the c_proj Linear; merge_cnt = one zeroed counter per (b, h)
     bf16_t* pl_out;
     int* merge_cnt;
+    // ... or, with part_tag [B][H][max_splits][66] given, split 0 merges: the other splits store (value, tag) words and
+    // split 0 polls them (see GemvArgs.sk_tag for the tag)
+    const unsigned* epoch;
+    unsigned launch_id;
+    unsigned long long* part_tag;
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t s);
 // Standalone merge (op tier): out[b][h*hd+d] = sum_s w_s o_s / sum_s w_s l_s
@@ -213,6 +225,7 @@ struct EmbedArgs {
     float* x;                // [B][E]
     bf16_t* pl_out;          // optional planes of pl_g * x for the first Linear of the lock-step batch (GemvArgs.pl_in)
     const float* pl_g;
+    unsigned* epoch;         // optional step counter behind the tagged hand-overs (GemvArgs.sk_tag): +1 when a step starts
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
     unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
 };
