@@ -1516,15 +1516,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // Arguments: everything an address of the up-front loads depends on sits in the first 16 dwords, which the hardware
 // preloads into SGPRs at wave launch (-amdgpu-kernarg-preload-count=16); fields of the GemvArgs block behind them cost a
 // scalar load from the kernarg segment first, ~2 k ticks on a cold launch (the first version took W alone as a leading
-// argument and spent 3.4 k of its 7.4 k ticks before the last load was issued).  nk = N | K << 16 (K = slice width),
-// flags = M | prologue << 4 | epilogue << 8, e0 / e1 / e2 = the epilogue's per-column operands: (c2, c3, -) behind a
-// folded LayerNorm, (bias, residual, gain of the planes written) otherwise; x rows are K apart, residual rows N apart.
+// argument and spent 3.4 k of its 7.4 k ticks before the last load was issued).  14 dwords are preloaded (16 user SGPRs less
+// the kernarg pointer): W, pl_in, xg, nk, flags, e0, e1, cp = 14.  nk = N | K << 16 (K = slice width), flags = M |
+// prologue << 4 | epilogue << 8; behind a folded LayerNorm xg = x (rows K apart, for the statistics), e0 = c2, e1 = c3;
+// otherwise xg = gain of the planes written (or null), e0 = bias, e1 = residual (rows N apart); cp = the step control
+// block (sequence length of the KV append) or, for K slices, the epoch word of the tags — always a readable address.
+// Fields of the argument block that the tail of the kernel needs are touched right behind the vector loads (ZG_PIN):
+// the compiler issues a scalar load where a field is first used and waits for it on the spot, which put two to three
+// scalar round trips into the epilogue and one in front of the barrier.
+#define ZG_PIN(v) asm volatile("" ::"s"(v))
 template <int KP, int KSL>
 __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ pl_in,
-                                                       const float* __restrict__ x, unsigned nk, unsigned flags,
+                                                       const float* __restrict__ xg, unsigned nk, unsigned flags,
                                                        const float* __restrict__ e0, const float* __restrict__ e1,
-                                                       const float* __restrict__ e2, const void* __restrict__ cp,
-                                                       const GemvArgs a) {
+                                                       const void* __restrict__ cp, const GemvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_stat[16];           // [8 rows][sum, sum of squares]
     __shared__ __attribute__((aligned(16))) float s_part[4 * 32 * 4];   // [wave][lane < 32][4]
     __shared__ __attribute__((aligned(16))) char s_slot[4 * KP * 2048];  // transposing slots: one per wave and pair
@@ -1565,9 +1570,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             }
         }
     }
-    // cp: the step control block (sequence length for the KV append), or, for K slices, the epoch word of the tags
-    const int T = (KSL == 1 && cp) ? static_cast<const StepCtrl*>(cp)->seq_len : 1;
-    const unsigned tag = (KSL > 1 && a.sk_tag) ? ((*static_cast<const unsigned*>(cp) << 8) | a.launch_id) : 0u;
+    const unsigned cpw = static_cast<const unsigned*>(cp)[KSL == 1 ? 1 : 0];  // StepCtrl.seq_len, or the epoch
     const bool ln = prologue == PRO_LAYERNORM;
     const int n = tile * 16 + brow, nc = min(n, N - 1);
     const int m_out = (bq & 1) * 4 + wave, mc = min(m_out, M - 1);
@@ -1578,7 +1581,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     } else {
         if (e0) e_bias = e0[nc];
         if (e1) e_res = e1[(size_t)mc * N + nc];
-        if (e2) e_g = e2[nc];
+        if (xg) e_g = xg[nc];
     }
     f32x4 xv[2][KP];  // LayerNorm statistics: this wave sums rows wave and wave + 4
     if (ln) {
@@ -1586,8 +1589,19 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int t = 0; t < KP; ++t)
-                xv[j][t] = reinterpret_cast<const f32x4*>(x + (size_t)min(wave + 4 * j, M - 1) * K)[min(lane + 64 * t, nq - 1)];
+                xv[j][t] = reinterpret_cast<const f32x4*>(xg + (size_t)min(wave + 4 * j, M - 1) * K)[min(lane + 64 * t, nq - 1)];
     }
+    {   // the argument-block fields of the tail, fetched under the vector loads
+        ZG_PIN(a.progress); ZG_PIN(a.pl_out); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
+        if (epilogue == EPI_QKV) {
+            ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_f16);
+        }
+        if constexpr (KSL > 1) {
+            ZG_PIN(a.sk_tag); ZG_PIN(a.launch_id); ZG_PIN(a.sk_ws); ZG_PIN(a.sk_cnt);
+        }
+    }
+    const int T = (int)cpw;
+    const unsigned tag = (cpw << 8) | a.launch_id;
 
     ZG_STAMP(1);
     // ---- MFMAs: weights -> B fragments through the slot (row rho x 8 pieces of 16 B, piece p at p ^ ((rho >> 1) & 7))
@@ -1653,7 +1667,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int w = 0; w < 4; ++w) y += s_part[(w * 32 + (lane & 31)) * 4 + wave];
     bool run = true;
-    if (KSL > 1 && a.sk_tag) {
+    if (KSL > 1 && a.sk_tag != nullptr) {
         // Tagged hand-over: slices 1.. store (value, tag) words and are done; slice 0 polls them and adds in slice order —
         // one memory-side round trip behind the slowest slice instead of the three of the ticket below.
         typedef unsigned long long u64;
@@ -1711,7 +1725,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         const float out = epilogue_row(a, m_out, n, y, e_bias, e_res, T - 1, nobest);
         if (a.pl_out) {  // the next Linear reads this row as planes (of g * y when a LayerNorm follows)
             uint32_t hi, mid, lo;
-            split3_pk(e2 ? out * e_g : out, 0.0f, hi, mid, lo);
+            split3_pk((!ln && xg) ? out * e_g : out, 0.0f, hi, mid, lo);
             a.pl_out[plane_elem(0, m_out, n)] = (bf16_t)hi;
             a.pl_out[plane_elem(1, m_out, n)] = (bf16_t)mid;
             a.pl_out[plane_elem(2, m_out, n)] = (bf16_t)lo;
@@ -1986,16 +2000,16 @@ int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
     const unsigned flags = (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8);
     const float* e0 = ln ? a.ln_c2 : a.bias;
     const float* e1 = ln ? a.ln_c3 : (a.epilogue == EPI_RESIDUAL ? a.resid : nullptr);
-    const float* e2 = (!ln && a.pl_out) ? a.pl_g : nullptr;
+    const float* xg = ln ? a.x : (a.pl_out ? a.pl_g : nullptr);
     const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
     if (ksl == 4) {
         GemvArgs b = a;
         if (b.epoch == nullptr || b.launch_id == 0 || b.launch_id > 255) b.sk_tag = nullptr;  // tickets
-        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2,
-                           static_cast<const void*>(b.sk_tag ? b.epoch : nullptr), b);
+        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 4>), dim3(grid, 4), dim3(256), 0, s, W, a.pl_in, xg, nk, flags, e0, e1,
+                           static_cast<const void*>(b.sk_tag ? b.epoch : reinterpret_cast<const unsigned*>(a.zero)), b);
     } else {
-        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, W, a.pl_in, a.x, nk, flags, e0, e1, e2,
-                           static_cast<const void*>(a.ctrl), a);
+        hipLaunchKernelGGL((gemv_pl4_kernel<KP, 1>), dim3(grid), dim3(256), 0, s, W, a.pl_in, xg, nk, flags, e0, e1,
+                           a.ctrl ? static_cast<const void*>(a.ctrl) : static_cast<const void*>(a.zero), a);
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
