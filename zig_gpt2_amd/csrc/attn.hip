@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "zg_kernels.h"
+#include "zg_runtime.h"
 
 namespace zg {
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ float row16_reduce_scatter(float (&s)[16], int lr) {
 // them, take a ticket, read back with agent-scope loads: the fence-free pattern of the split-K Linears (gemv.hip).
 __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h, int split, int lane, float o, float M, float l,
                                                 unsigned tag) {
-    float* part = a.part + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
+    float* part = a.part + (((size_t)b * (int)gridDim.x + h) * a.max_splits + split) * kPartStride;
     if (a.pl_out == nullptr) {
         part[lane] = o;
         if (lane == 0) {
@@ -113,7 +114,7 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
         // trip behind the slowest split instead of the three of the ticket below (drain, ticket, read back).
         typedef unsigned long long u64;
         auto pack = [&](float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); };
-        u64* pt = a.part_tag + (((size_t)b * a.n_heads + h) * a.max_splits + split) * kPartStride;
+        u64* pt = a.part_tag + (((size_t)b * (int)gridDim.x + h) * a.max_splits + split) * kPartStride;
         if (split != 0) {
             __hip_atomic_store(pt + lane, pack(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) {
@@ -188,13 +189,13 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
             __hip_atomic_store(gp + 65, __float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int* cnt = a.merge_cnt + b * a.n_heads + h;
+        int* cnt = a.merge_cnt + b * (int)gridDim.x + h;
         int ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket != nsplit - 1) return;
         if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-        const gu32* p0 = (const gu32*)(a.part + ((size_t)b * a.n_heads + h) * a.max_splits * kPartStride);
+        const gu32* p0 = (const gu32*)(a.part + ((size_t)b * (int)gridDim.x + h) * a.max_splits * kPartStride);
         constexpr int MAXS = 4;  // ctx 1024 / 256; more splits take the loop below
         if (nsplit <= MAXS) {
             float ms[MAXS], ls[MAXS], os[MAXS];
@@ -241,18 +242,28 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
 }
 
 // grid (H, max_splits, B), block 256.  Requires head_dim == 64.
+// Arguments (zg_common.h ZG_PIN): the 14 preloaded dwords carry everything a K/V address depends on — q, k, v, the three
+// strides (32-bit element counts; bit 31 of st = "sequence length from the control block"), t_hi — plus the two words
+// read through a pointer, cw = step control block and ew = epoch of the tags (always readable addresses).  The first
+// version took the AttnArgs block alone: its K/V loads were issued behind two dependent scalar round trips (kernarg
+// block, then the sequence length behind the control-block pointer in it).
 template <typename KV>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qp, const void* __restrict__ kp,
+                                                          const void* __restrict__ vp, unsigned sb, unsigned sh, unsigned st,
+                                                          int t_hi, const int* __restrict__ cw, const unsigned* __restrict__ ew,
+                                                          const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_o[4][64];
     __shared__ float s_m[4], s_l[4];
     const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    const int n_heads = (int)gridDim.x;
     // t_hi: launch-time upper bound of the sequence length (seq_len itself in the op tier, the
     // 64-position bucket of the captured graph in the model tier).  Every K/V load below depends
     // only on t_hi, so it is in flight while the exact seq_len is still being fetched from the
     // device control block; seq_len is needed for masking alone.
-    const int t_hi = a.t_hi;
-    const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
-    const unsigned tag = a.part_tag ? ((*a.epoch << 8) | a.launch_id) : 0u;  // tagged hand-over of the split partials
+    const int Tc = cw[1];
+    const unsigned epoch = ew[0];
+    const int T = (st >> 31) ? Tc : t_hi;
+    const size_t stride_t = st & 0x7fffffffu;
     const int chunk0 = split * kAttnChunk;
     if (chunk0 >= t_hi) return;  // nothing to attend to in this split (consumer skips it too)
 
@@ -260,9 +271,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     const int lr = lane & 15, g = lane >> 4;
     const int base = chunk0 + wave * 64;
 
-    const KV* K = reinterpret_cast<const KV*>(a.k) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
-    const KV* V = reinterpret_cast<const KV*>(a.v) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + ((size_t)b * a.n_heads + h) * 64 + lr * 4);
+    const KV* K = reinterpret_cast<const KV*>(kp) + (size_t)b * sb + (size_t)h * sh;
+    const KV* V = reinterpret_cast<const KV*>(vp) + (size_t)b * sb + (size_t)h * sh;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + ((size_t)b * n_heads + h) * 64 + lr * 4);
     const float alpha = 0.125f;  // 1 / sqrt(64), applied to the dot product like sgemm alpha (ops.zig:275)
 
     float m_w = kNegBig, l_w = 0.0f;
@@ -274,13 +285,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int t = base + 4 * i + g;
             if (t < t_hi) {
-                k4[i] = load_kv4<KV>(K + (size_t)t * a.stride_t + lr * 4);
-                v4[i] = load_kv4<KV>(V + (size_t)t * a.stride_t + lr * 4);
+                k4[i] = load_kv4<KV>(K + (size_t)t * stride_t + lr * 4);
+                v4[i] = load_kv4<KV>(V + (size_t)t * stride_t + lr * 4);
             } else {
                 k4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 v4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         }
+        ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt);
         pf_count(a.progress);
         // ---- partial dots, then reduce-scatter: lane (g, j) ends with the score of t = base + 4*j + g
         float s[16];
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
             o = fmaf(sc, s_o[w][lane], o);
             l = fmaf(sc, s_l[w], l);
         }
-        publish_partial(a, b, h, split, lane, o, M, l, tag);
+        publish_partial(a, b, h, split, lane, o, M, l, (epoch << 8) | a.launch_id);
     }
 }
 
@@ -373,22 +385,27 @@ __device__ __forceinline__ float grp8_reduce_scatter(float (&s)[8], int c) {
     return keep + (hi ? from_lo : from_hi);
 }
 
-__global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __restrict__ qp0, const void* __restrict__ kp,
+                                                             const void* __restrict__ vp, unsigned sb, unsigned sh, unsigned st,
+                                                             int t_hi, const int* __restrict__ cw, const unsigned* __restrict__ ew,
+                                                             const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_o[4][64];
     __shared__ float s_m[4], s_l[4];
     const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
-    const int t_hi = a.t_hi;
-    const int T = a.ctrl ? a.ctrl->seq_len : a.seq_len;
-    const unsigned tag = a.part_tag ? ((*a.epoch << 8) | a.launch_id) : 0u;  // tagged hand-over of the split partials
+    const int n_heads = (int)gridDim.x;
+    const int Tc = cw[1];
+    const unsigned epoch = ew[0];
+    const int T = (st >> 31) ? Tc : t_hi;
+    const size_t stride_t = st & 0x7fffffffu;
     const int chunk0 = split * kAttnChunk;
     if (chunk0 >= t_hi) return;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 7, g8 = lane >> 3;
     const int base = chunk0 + wave * 64;
-    const _Float16* K = reinterpret_cast<const _Float16*>(a.k) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
-    const _Float16* V = reinterpret_cast<const _Float16*>(a.v) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
-    const float* qp = a.q + ((size_t)b * a.n_heads + h) * 64 + c * 8;
+    const _Float16* K = reinterpret_cast<const _Float16*>(kp) + (size_t)b * sb + (size_t)h * sh;
+    const _Float16* V = reinterpret_cast<const _Float16*>(vp) + (size_t)b * sb + (size_t)h * sh;
+    const float* qp = qp0 + ((size_t)b * n_heads + h) * 64 + c * 8;
     const f32x4 qa = *reinterpret_cast<const f32x4*>(qp), qb = *reinterpret_cast<const f32x4*>(qp + 4);
     const float q[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
     const float alpha = 0.125f;
@@ -402,13 +419,14 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
         for (int i = 0; i < 8; ++i) {
             const int t = base + 8 * i + g8;
             if (t < t_hi) {
-                k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * a.stride_t + c * 8);
-                v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * a.stride_t + c * 8);
+                k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * stride_t + c * 8);
+                v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * stride_t + c * 8);
             } else {
                 k8[i] = zero8;
                 v8[i] = zero8;
             }
         }
+        ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt);
         pf_count(a.progress);
         float s[8];
 #pragma unroll
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const AttnArgs a) {
             ov = fmaf(sc, s_o[w][lane], ov);
             l = fmaf(sc, s_l[w], l);
         }
-        publish_partial(a, b, h, split, lane, ov, M, l, tag);
+        publish_partial(a, b, h, split, lane, ov, M, l, (epoch << 8) | a.launch_id);
     }
 }
 
@@ -493,10 +511,19 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     const int splits = (a.t_hi + kAttnChunk - 1) / kAttnChunk;
     ZG_REQUIRE(splits <= a.max_splits, ZG_ERR_ARG, "attention: t_hi %d needs %d splits > %d", a.t_hi, splits, a.max_splits);
     dim3 grid(a.n_heads, splits, a.batch);
+    ZG_REQUIRE(a.stride_b >= 0 && a.stride_h >= 0 && a.stride_t >= 0 && a.stride_b < (1ll << 32) && a.stride_h < (1ll << 32) && a.stride_t < (1ll << 31),
+               ZG_ERR_UNSUPPORTED, "attention: strides beyond 32 bits");
+    ZG_REQUIRE(a.part_tag == nullptr || a.epoch != nullptr, ZG_ERR_ARG, "attention: tagged partials without an epoch word");
+    const unsigned sb = (unsigned)a.stride_b, sh = (unsigned)a.stride_h, st = (unsigned)a.stride_t | (a.ctrl ? 0x80000000u : 0u);
+    const int* cw = a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(ctx().d_zero);
+    const unsigned* ew = a.epoch ? a.epoch : reinterpret_cast<const unsigned*>(ctx().d_zero);
     static const bool h8_off = getenv("ZGPT2_NO_KV_H8") != nullptr;  // A/B: the fp16 cache on the fp32 lane map (8-byte loads)
-    if (a.kv_f16 && a.stride_t == 64 && !h8_off) hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a);
-    else if (a.kv_f16) hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a);
+    if (a.kv_f16 && a.stride_t == 64 && !h8_off)
+        hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, a.t_hi, cw, ew, a);
+    else if (a.kv_f16)
+        hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, a.t_hi, cw, ew, a);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, a.t_hi, cw, ew, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -660,7 +660,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
 // meet in LDS after the arithmetic, where one thread per row runs the epilogue.
 template <typename WT, int LPR, int CPL, int NP = 2>  // NP passes of 64 / LPR rows per workgroup
 __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N,
-                                                          int K, int epilogue, int merge_splits, const GemvArgs a) {
+                                                          int K, unsigned em, const float* __restrict__ part_in, int max_splits,
+                                                          const float* __restrict__ bias, const float* __restrict__ resid,
+                                                          const GemvArgs a) {
+    // 14 preloaded dwords: Wv, xin, N, K, em = epilogue | merge_splits << 8 | has_bias << 16 | has_resid << 17, the
+    // attention partials and their split stride, bias and residual (a few zero floats when absent: read at index 0)
+    const int epilogue = (int)(em & 0xffu), merge_splits = (int)((em >> 8) & 0xffu);
+    const int has_bias = (int)((em >> 16) & 1u), has_resid = (int)((em >> 17) & 1u);
     // merge_splits > 0 (attn c_proj): the input is the head merge of the attention partials — every lane combines
     // the <= 4 split partials of ITS OWN 8-element chunks (a chunk lies inside one head), all loads issued with the
     // weights; no shared strip, no barrier in front of the FMAs (the merge through an LDS strip cost 3.9 us per
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
         for (int i = 0; i < CPL; ++i) {
             const int e0 = wave * Kq + min(lr + LPR * i, nchq - 1) * 8;
             const int h = e0 >> 6, d0 = e0 & 63;  // head_dim 64
-            const float* p = a.part + ((size_t)h * a.max_splits) * kPartStride;
+            const float* p = part_in + ((size_t)h * max_splits) * kPartStride;
             float ms[MAXS], ls[MAXS];
             W8 o[MAXS];
 #pragma unroll
@@ -726,9 +732,11 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
     float bias_n = 0.0f, resid_n = 0.0f;
     if (tid < ROWS) {
         const int n = min(row0 + tid, N - 1);
-        bias_n = *(a.bias ? a.bias + n : a.zero);
-        resid_n = *(epilogue == EPI_RESIDUAL ? a.resid + n : a.zero);
+        bias_n = bias[n * has_bias];
+        resid_n = resid[n * has_resid];
     }
+    ZG_PIN(a.y);  // the tail's argument-block fields, fetched under the vector loads (zg_common.h ZG_PIN)
+    ZG_PIN(a.progress);
     pf_count(a.progress);
 #pragma unroll
     for (int i = 0; i < CPL; ++i)
@@ -764,12 +772,15 @@ template <typename WT>
 int launch_ksplit(const GemvArgs& a, hipStream_t s) {
     const int nchq = a.K / 32;  // 16-B chunks per quarter row
     const int merge_splits = a.prologue == PRO_ATTN_MERGE ? (a.t_hi + kAttnChunk - 1) / kAttnChunk : 0;
+    const unsigned has_resid = a.epilogue == EPI_RESIDUAL ? 1u : 0u;
+    const unsigned em = (unsigned)a.epilogue | ((unsigned)merge_splits << 8) | ((a.bias ? 1u : 0u) << 16) | (has_resid << 17);
     // two passes of 64 / LPR rows per workgroup (four measured slower: 2.65 -> 3.3 us for mlp c_proj)
 #define ZG_KS(LPR_, CPL_)                                                                                                \
     {                                                                                                                    \
         constexpr int rows = 2 * (64 / LPR_);                                                                            \
         hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_, 2>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
-                           a.N, a.K, a.epilogue, merge_splits, a);                                                       \
+                           a.N, a.K, em, a.part ? a.part : a.zero, a.max_splits, a.bias ? a.bias : a.zero,              \
+                           has_resid ? a.resid : a.zero, a);                                                             \
         ZG_HIP(hipGetLastError());                                                                                       \
         return ZG_OK;                                                                                                    \
     }
@@ -809,10 +820,13 @@ bool gemv_use_ksplit(const GemvArgs& a) {
 // its first FMA.  (Same real-number result; in floating point r (S1 - mu c2) cancels when |mu| >> sigma, which costs
 // log2(|mu| / sigma) bits of the fp32 product sums — far inside the 1e-3 bound for any LayerNorm input.)
 template <typename WT, int LPR, int CPL, int NP = 2>  // NP passes of 64 / LPR rows per workgroup
-__global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, int N, int K,
-                                                       int epilogue, const float* __restrict__ ln_g,
-                                                       const float* __restrict__ c2, const float* __restrict__ c3,
+__global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, unsigned ne, int K,
+                                                       const float* __restrict__ ln_g, const float* __restrict__ c2,
+                                                       const float* __restrict__ c3, const int* __restrict__ cw,
                                                        const GemvArgs a) {
+    // 14 preloaded dwords: Wv, xin, ne = N | epilogue << 24, K, ln_g, c2, c3, cw = the step control block (always a
+    // readable address: its second word is the sequence length of the KV append)
+    const int N = (int)(ne & 0xffffffu), epilogue = (int)(ne >> 24);
     constexpr int RPP = 64 / LPR, ROWS = NP * RPP;
     __shared__ float part[4][ROWS];
     __shared__ float stat[4][2];
@@ -853,7 +867,13 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         c2n = c2[n];
         c3n = c3[n];
     }
-    const int T = a.ctrl ? a.ctrl->seq_len : 1;  // KV append position (EPI_QKV)
+    const int T = cw[1];  // KV append position (EPI_QKV)
+    {   // the argument-block fields of the tail, fetched under the vector loads (zg_common.h ZG_PIN)
+        ZG_PIN(a.progress); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
+        if (epilogue == EPI_QKV) {
+            ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_f16);
+        }
+    }
     pf_count(a.progress);
     // statistics of this wave's quarter (every LPR-lane group holds the whole quarter) and z = g x
     float sx = 0.0f, sxx = 0.0f;
@@ -938,7 +958,8 @@ int launch_lnk(const GemvArgs& a, hipStream_t s) {
     {                                                                                                                  \
         constexpr int rows = 4 * (64 / LPR_);                                                                          \
         hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_, 4>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
-                           a.N, a.K, a.epilogue, a.ln_g, a.ln_c2, a.ln_c3, a);                                         \
+                           (unsigned)a.N | ((unsigned)a.epilogue << 24), a.K, a.ln_g, a.ln_c2, a.ln_c3,                 \
+                           a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a);   \
         ZG_HIP(hipGetLastError());                                                                                     \
         return ZG_OK;                                                                                                  \
     }
@@ -1524,7 +1545,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // Fields of the argument block that the tail of the kernel needs are touched right behind the vector loads (ZG_PIN):
 // the compiler issues a scalar load where a field is first used and waits for it on the spot, which put two to three
 // scalar round trips into the epilogue and one in front of the barrier.
-#define ZG_PIN(v) asm volatile("" ::"s"(v))
 template <int KP, int KSL>
 __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ pl_in,
                                                        const float* __restrict__ xg, unsigned nk, unsigned flags,

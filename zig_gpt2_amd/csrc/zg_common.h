@@ -75,6 +75,15 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& hi, uint
 constexpr int kPlaneStep = 3 * 8 * 32;  // elements per 32-k step
 __host__ __device__ inline size_t plane_elem(int p, int m, int k) { return ((size_t)((k >> 5) * 3 + p) * 8 + m) * 32 + (k & 31); }
 
+// Kernel-argument hygiene of the decode kernels.  Only the first 14 dwords of the arguments are preloaded into SGPRs at
+// wave launch (-amdgpu-kernarg-preload-count=16, two of them hold the kernarg pointer); any other field costs a scalar
+// load from the kernarg segment, which the compiler issues where the field is first used and waits for on the spot — a
+// cold round trip to memory in a real decode step (every launch has its own argument block).  So (1) whatever an
+// address of the up-front vector loads depends on travels in the leading arguments, and (2) fields that the tail of a
+// kernel needs are touched with ZG_PIN right behind the vector loads: their scalar loads then complete under the vector
+// memory latency instead of in the epilogue.
+#define ZG_PIN(v) asm volatile("" ::"s"(v))
+
 // DPP row rotate inside each 16-lane row: every lane reads the lane `n` to its right (cyclic).
 template <int N>
 __device__ __forceinline__ float dpp_row_ror(float v) {
