@@ -96,9 +96,9 @@ __device__ __forceinline__ float row16_reduce_scatter(float (&s)[16], int lr) {
 // in split order, one reciprocal — and writes the head's 64 outputs as the three bf16 planes the c_proj Linear loads as
 // MFMA A fragments (zg_common.h plane_elem).  Publish with write-through (agent-scope relaxed atomic) stores, drain
 // them, take a ticket, read back with agent-scope loads: the fence-free pattern of the split-K Linears (gemv.hip).
-__device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h, int split, int lane, float o, float M, float l,
-                                                unsigned tag) {
-    float* part = a.part + (((size_t)b * (int)gridDim.x + h) * a.max_splits + split) * kPartStride;
+__device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, int nsplit, int b, int h, int split, int lane, float o,
+                                                float M, float l, unsigned tag) {
+    float* part = a.part + (((size_t)b * n_heads + h) * a.max_splits + split) * kPartStride;
     if (a.pl_out == nullptr) {
         part[lane] = o;
         if (lane == 0) {
@@ -107,14 +107,14 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
         }
         return;
     }
-    const int nsplit = (int)gridDim.y;  // every launched split publishes (those beyond seq_len with weight 0)
+    // nsplit = the launched splits: every one of them publishes
     float r = o, lsum = l;
     if (nsplit > 1 && a.part_tag) {
         // Tagged hand-over: splits 1.. store (value, tag) words and are done; split 0 polls them — one memory-side round
         // trip behind the slowest split instead of the three of the ticket below (drain, ticket, read back).
         typedef unsigned long long u64;
         auto pack = [&](float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); };
-        u64* pt = a.part_tag + (((size_t)b * (int)gridDim.x + h) * a.max_splits + split) * kPartStride;
+        u64* pt = a.part_tag + (((size_t)b * n_heads + h) * a.max_splits + split) * kPartStride;
         if (split != 0) {
             __hip_atomic_store(pt + lane, pack(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) {
@@ -189,13 +189,13 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
             __hip_atomic_store(gp + 65, __float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int* cnt = a.merge_cnt + b * (int)gridDim.x + h;
+        int* cnt = a.merge_cnt + b * n_heads + h;
         int ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket != nsplit - 1) return;
         if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-        const gu32* p0 = (const gu32*)(a.part + ((size_t)b * (int)gridDim.x + h) * a.max_splits * kPartStride);
+        const gu32* p0 = (const gu32*)(a.part + ((size_t)b * n_heads + h) * a.max_splits * kPartStride);
         constexpr int MAXS = 4;  // ctx 1024 / 256; more splits take the loop below
         if (nsplit <= MAXS) {
             float ms[MAXS], ls[MAXS], os[MAXS];
@@ -243,19 +243,19 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int b, int h,
 
 // grid (H, max_splits, B), block 256.  Requires head_dim == 64.
 // Arguments (zg_common.h ZG_PIN): the 14 preloaded dwords carry everything a K/V address depends on — q, k, v, the three
-// strides (32-bit element counts; bit 31 of st = "sequence length from the control block"), t_hi — plus the two words
+// strides (32-bit element counts; bit 31 of st = "sequence length from the control block"), th = t_hi | heads << 20 — plus the two words
 // read through a pointer, cw = step control block and ew = epoch of the tags (always readable addresses).  The first
 // version took the AttnArgs block alone: its K/V loads were issued behind two dependent scalar round trips (kernarg
 // block, then the sequence length behind the control-block pointer in it).
 template <typename KV>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qp, const void* __restrict__ kp,
                                                           const void* __restrict__ vp, unsigned sb, unsigned sh, unsigned st,
-                                                          int t_hi, const int* __restrict__ cw, const unsigned* __restrict__ ew,
+                                                          unsigned th, const int* __restrict__ cw, const unsigned* __restrict__ ew,
                                                           const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_o[4][64];
     __shared__ float s_m[4], s_l[4];
     const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
-    const int n_heads = (int)gridDim.x;
+    const int t_hi = (int)(th & 0xfffffu), n_heads = (int)(th >> 20);  // (grid sizes are scalar loads from the kernarg segment)
     // t_hi: launch-time upper bound of the sequence length (seq_len itself in the op tier, the
     // 64-position bucket of the captured graph in the model tier).  Every K/V load below depends
     // only on t_hi, so it is in flight while the exact seq_len is still being fetched from the
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             o = fmaf(sc, s_o[w][lane], o);
             l = fmaf(sc, s_l[w], l);
         }
-        publish_partial(a, b, h, split, lane, o, M, l, (epoch << 8) | a.launch_id);
+        publish_partial(a, n_heads, (t_hi + kAttnChunk - 1) / kAttnChunk, b, h, split, lane, o, M, l, (epoch << 8) | a.launch_id);
     }
 }
 
@@ -387,12 +387,12 @@ __device__ __forceinline__ float grp8_reduce_scatter(float (&s)[8], int c) {
 
 __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __restrict__ qp0, const void* __restrict__ kp,
                                                              const void* __restrict__ vp, unsigned sb, unsigned sh, unsigned st,
-                                                             int t_hi, const int* __restrict__ cw, const unsigned* __restrict__ ew,
+                                                             unsigned th, const int* __restrict__ cw, const unsigned* __restrict__ ew,
                                                              const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float s_o[4][64];
     __shared__ float s_m[4], s_l[4];
     const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
-    const int n_heads = (int)gridDim.x;
+    const int t_hi = (int)(th & 0xfffffu), n_heads = (int)(th >> 20);  // (grid sizes are scalar loads from the kernarg segment)
     const int Tc = cw[1];
     const unsigned epoch = ew[0];
     const int T = (st >> 31) ? Tc : t_hi;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
             ov = fmaf(sc, s_o[w][lane], ov);
             l = fmaf(sc, s_l[w], l);
         }
-        publish_partial(a, b, h, split, lane, ov, M, l, (epoch << 8) | a.launch_id);
+        publish_partial(a, n_heads, (t_hi + kAttnChunk - 1) / kAttnChunk, b, h, split, lane, ov, M, l, (epoch << 8) | a.launch_id);
     }
 }
 
@@ -514,16 +514,18 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     ZG_REQUIRE(a.stride_b >= 0 && a.stride_h >= 0 && a.stride_t >= 0 && a.stride_b < (1ll << 32) && a.stride_h < (1ll << 32) && a.stride_t < (1ll << 31),
                ZG_ERR_UNSUPPORTED, "attention: strides beyond 32 bits");
     ZG_REQUIRE(a.part_tag == nullptr || a.epoch != nullptr, ZG_ERR_ARG, "attention: tagged partials without an epoch word");
+    ZG_REQUIRE(a.t_hi < (1 << 20) && a.n_heads < (1 << 12), ZG_ERR_UNSUPPORTED, "attention: t_hi %d / heads %d too large", a.t_hi, a.n_heads);
+    const unsigned th = (unsigned)a.t_hi | ((unsigned)a.n_heads << 20);
     const unsigned sb = (unsigned)a.stride_b, sh = (unsigned)a.stride_h, st = (unsigned)a.stride_t | (a.ctrl ? 0x80000000u : 0u);
     const int* cw = a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(ctx().d_zero);
     const unsigned* ew = a.epoch ? a.epoch : reinterpret_cast<const unsigned*>(ctx().d_zero);
     static const bool h8_off = getenv("ZGPT2_NO_KV_H8") != nullptr;  // A/B: the fp16 cache on the fp32 lane map (8-byte loads)
     if (a.kv_f16 && a.stride_t == 64 && !h8_off)
-        hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, a.t_hi, cw, ew, a);
+        hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     else if (a.kv_f16)
-        hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, a.t_hi, cw, ew, a);
+        hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     else
-        hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, a.t_hi, cw, ew, a);
+        hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

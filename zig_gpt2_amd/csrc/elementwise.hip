@@ -153,17 +153,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
     const int s = a.ctrl->step;
     const int mode = a.ctrl->mode;
     const int npart = a.n_partials;
-    if (a.progress != nullptr && a.finish_only == 0 && threadIdx.x == 0) {
-        // a step at sequence length s + 1 starts; block 0 of every launch of this queue lands on the XCD this block is on
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID
-        const unsigned long long word = ((unsigned long long)(0x100u | xcc) << 32) | (((unsigned)(s + 1) << 8) | 1u);
-        __hip_atomic_store(static_cast<unsigned long long*>(__builtin_assume_aligned(a.progress, 8)), word, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-#ifdef ZG_STAMPS
-        reinterpret_cast<PfCtl*>(a.progress)->xcd_log[0] = 0x100u | xcc;
-#endif
-    }
-    const int n_waves = blockDim.x >> 6;
+    const int n_waves = a.batch > 4 ? 8 : 4;  // as launched (blockDim is a scalar load from the kernarg segment)
     for (int b = wave; b < a.batch; b += n_waves) {
         // speculative fetch of this sequence's partial maxima (valid memory whether or not needed)
         float bv = -3.0e38f;
@@ -172,6 +162,20 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
             const float v = a.part_val[(size_t)b * a.part_stride + p];
             const int i = a.part_idx[(size_t)b * a.part_stride + p];
             if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+        {   // the argument-block fields used behind the partial-maxima loads (zg_common.h ZG_PIN)
+            ZG_PIN(a.forced); ZG_PIN(a.wte); ZG_PIN(a.wpe); ZG_PIN(a.weight_type); ZG_PIN(a.n_embed); ZG_PIN(a.cur_token); ZG_PIN(a.out_tokens);
+            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only);
+        }
+        if (b == 0 && a.progress != nullptr && a.finish_only == 0 && lane == 0) {
+            // a step at sequence length s + 1 starts; block 0 of every launch of this queue lands on the XCD this block is on
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID
+            const unsigned long long word = ((unsigned long long)(0x100u | xcc) << 32) | (((unsigned)(s + 1) << 8) | 1u);
+            __hip_atomic_store(static_cast<unsigned long long*>(__builtin_assume_aligned(a.progress, 8)), word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ZG_STAMPS
+            reinterpret_cast<PfCtl*>(a.progress)->xcd_log[0] = 0x100u | xcc;
+#endif
         }
         const int np = a.prompt_len ? a.prompt_len[b] : 0;
         const int p_cur = a.prompt[(size_t)b * a.prompt_stride + min(s, a.prompt_stride - 1)];
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
     if (a.finish_only == 1 || a.finish_only == 2) return;
     __syncthreads();
     const int total4 = a.batch * (a.n_embed >> 2);
-    for (int i = threadIdx.x; i < total4; i += blockDim.x) {
+    for (int i = threadIdx.x; i < total4; i += 64 * n_waves) {
         const int b = i / (a.n_embed >> 2), e = (i % (a.n_embed >> 2)) * 4;
         const int tok = s_tok[b];
         f32x4 o;

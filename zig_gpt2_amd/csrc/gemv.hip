@@ -322,9 +322,12 @@ __device__ __forceinline__ void ln_strip(const float* __restrict__ xin, const fl
 //   * passes are software-pipelined one deep (next pass in flight while this one is reduced).
 template <typename WT, int MT, int LPR, int CPL, bool ARGMAX>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, const float* __restrict__ xin,
-                                                   int N, int K, int M, int rows_per_wave, int prologue,
-                                                   int epilogue, const float* __restrict__ ln_g,
-                                                   const float* __restrict__ ln_b, const GemvArgs a) {
+                                                   int N, int K, unsigned mpew, int rows_per_wave,
+                                                   const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                   const int* __restrict__ cw, const GemvArgs a) {
+    // mpew = M | prologue << 4 | epilogue << 8 | waves per workgroup << 12 (blockDim is a scalar load from the kernarg
+    // segment: zg_common.h ZG_PIN); cw = the step control block, always a readable address
+    const int M = (int)(mpew & 15u), prologue = (int)((mpew >> 4) & 15u), epilogue = (int)((mpew >> 8) & 15u);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RPP = 64 / LPR;
     constexpr bool XREG = (MT == 1) && (CPL <= 8);  // input row cached in registers
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     const WT* W = reinterpret_cast<const WT*>(Wv);
     // M == 1: waves are independent (wave-private prologue), so the workgroup may be 1..4 waves: matrices with
     // few rows are launched as one-wave workgroups that the dispatcher spreads over all CUs
-    const int wpw = PERWAVE ? (int)(blockDim.x >> 6) : 4;
+    const int wpw = PERWAVE ? (int)(mpew >> 12) : 4;
     // A wide un-normalised input (mlp c_proj: K = 4 E) is as many bytes per wave as the wave's weight rows, so the
     // waves of a workgroup share ONE copy of it (a quarter of the fetch each, one barrier); everything else
     // keeps wave-private strips and no barrier.
@@ -356,7 +359,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ Wv, 
     ea = load_extra<MT>(a, epilogue, M, N, row_begin + rsub);
 
     // position-dependent scalar (consumed late: merge split count when t_hi == 0, KV scatter position)
-    const int T = a.ctrl ? a.ctrl->seq_len : 1;
+    const int T = max(cw[1], 1);
+    {   // the argument-block fields of the tail, fetched under the first weight loads (zg_common.h ZG_PIN)
+        ZG_PIN(a.progress); ZG_PIN(a.epilogue); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(__float_as_uint(a.eps));
+        if (ARGMAX) {
+            ZG_PIN(a.logits); ZG_PIN(a.logits_stride); ZG_PIN(a.part_val); ZG_PIN(a.part_idx); ZG_PIN(gridDim.x);
+        }
+    }
     pf_count(a.progress);
     ZG_STAMP(1);
 
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         c2n = c2[n];
         c3n = c3[n];
     }
-    const int T = cw[1];  // KV append position (EPI_QKV)
+    const int T = max(cw[1], 1);  // KV append position (EPI_QKV)
     {   // the argument-block fields of the tail, fetched under the vector loads (zg_common.h ZG_PIN)
         ZG_PIN(a.progress); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
         if (epilogue == EPI_QKV) {
@@ -2084,7 +2093,8 @@ int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
     }
     ZG_REQUIRE(lds <= 160 * 1024, ZG_ERR_UNSUPPORTED, "gemv: M=%d x K=%d does not fit LDS", a.M, a.K);
     hipLaunchKernelGGL((gemv_kernel<WT, MT, LPR, CPL, ARGMAX>), dim3(grid), dim3(64 * wpw), lds, s, a.W, a.x, a.N, a.K,
-                       a.M, a.rows_per_wave, a.prologue, a.epilogue, a.ln_g, a.ln_b, a);
+                       (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8) | ((unsigned)wpw << 12), a.rows_per_wave,
+                       a.ln_g, a.ln_b, a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

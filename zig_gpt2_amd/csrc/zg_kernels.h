@@ -206,22 +206,25 @@ int launch_sample(float* logits, int batch, int vocab, float temp, const float* 
 // Decode-step head kernel: token selection (+ argmax finalisation of the previous step) and
 // x = wte[token] + wpe[pos].
 struct EmbedArgs {
+    // the first 14 dwords are preloaded into SGPRs (zg_common.h ZG_PIN): what the first loads of the kernel depend on
     StepCtrl* ctrl;
-    const void* wte;  // [V][E] bf16 or fp32
-    const void* wpe;  // [ctx][E]
-    int weight_type;
-    int n_embed, batch, vocab;
-    const int* prompt;       // [B][prompt_stride]
-    int prompt_stride;
-    const int* prompt_len;   // [B]
-    const int* forced;       // [B] (mode 1)
-    int* cur_token;          // [B]
-    int* out_tokens;         // [B][out_stride]
-    int out_stride;
     const float* part_val;   // [B][n_partials]
     const int* part_idx;
     int part_stride;
     int n_partials;          // lm_head grid size
+    const int* prompt;       // [B][prompt_stride]
+    const int* prompt_len;   // [B]
+    int batch;
+    int prompt_stride;
+    // ... the rest is fetched from the kernarg segment under those loads
+    const int* forced;       // [B] (mode 1)
+    const void* wte;  // [V][E] bf16 or fp32
+    const void* wpe;  // [ctx][E]
+    int weight_type;
+    int n_embed, vocab;
+    int* cur_token;          // [B]
+    int* out_tokens;         // [B][out_stride]
+    int out_stride;
     float* x;                // [B][E]
     bf16_t* pl_out;          // optional planes of pl_g * x for the first Linear of the lock-step batch (GemvArgs.pl_in)
     const float* pl_g;
