@@ -1586,17 +1586,19 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             wq[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p1 + qc * 64));
         }
     }
-    u32x4 af[6 * KP];  // [pair][step of the pair][plane]; tile rows 8..15 have no batch row behind them: zeros
+    // A fragments: tile rows 8..15 have no batch row behind them (their outputs, lanes 32..63 of the accumulators, are
+    // never read), so lanes 8..15 of every 16-lane row fetch the SECOND step of the pair while lanes 0..7 fetch the first:
+    // one full-wave load per (pair, plane) instead of two half-empty ones — the vector-memory issue slots, shared by the
+    // four waves, were what the entry phase of this kernel waited for.  The second step's operand is the same register
+    // rotated by 8 lanes inside the rows (DPP row_ror:8).
+    u32x4 af[3 * KP];  // [pair][plane]
     {
         const bf16_t* pin = pl_in + (KSL > 1 ? (size_t)blockIdx.y * (K >> 5) * kPlaneStep : (size_t)0) + (lane & 7) * 32 + bq * 8;
 #pragma unroll
-        for (int i = 0; i < 2 * KP; ++i) {
-            const int st = 2 * min(wave + 4 * (i >> 1), npairs - 1) + (i & 1);
+        for (int i = 0; i < KP; ++i) {
+            const int st = 2 * min(wave + 4 * i, npairs - 1) + ((lane >> 3) & 1);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                af[i * 3 + p] = u32x4{0u, 0u, 0u, 0u};
-                if ((lane & 8) == 0) af[i * 3 + p] = *reinterpret_cast<const u32x4*>(pin + (size_t)(st * 3 + p) * 256);
-            }
+            for (int p = 0; p < 3; ++p) af[i * 3 + p] = *reinterpret_cast<const u32x4*>(pin + (size_t)(st * 3 + p) * 256);
         }
     }
     const unsigned cpw = static_cast<const unsigned*>(cp)[KSL == 1 ? 1 : 0];  // StepCtrl.seq_len, or the epoch
@@ -1659,8 +1661,12 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         const mf_bf16x8 b0 = __builtin_bit_cast(mf_bf16x8, bv[2 * i]), b1 = __builtin_bit_cast(mf_bf16x8, bv[2 * i + 1]);
 #pragma unroll
         for (int p = 2; p >= 0; --p) {  // smallest plane first
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, af[(2 * i) * 3 + p]), b0, acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, af[(2 * i + 1) * 3 + p]), b1, acc1, 0, 0, 0);
+            const u32x4 r = af[i * 3 + p];
+            u32x4 r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r1[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r[j], 0x128, 0xF, 0xF, true);  // row_ror:8
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, r), b0, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, r1), b1, acc1, 0, 0, 0);
         }
     }
     ZG_STAMP(2);
