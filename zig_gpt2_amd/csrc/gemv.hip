@@ -1549,7 +1549,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // argument and spent 3.4 k of its 7.4 k ticks before the last load was issued).  14 dwords are preloaded (16 user SGPRs less
 // the kernarg pointer): W, pl_in, xg, nk, flags, e0, e1, cp = 14.  nk = N | K << 16 (K = slice width), flags = M |
 // prologue << 4 | epilogue << 8; behind a folded LayerNorm xg = x (rows K apart, for the statistics), e0 = c2, e1 = c3;
-// otherwise xg = gain of the planes written (or null), e0 = bias, e1 = residual (rows N apart); cp = the step control
+// otherwise xg = gain of the planes written, e0 = bias, e1 = residual (rows N apart) — a few zero floats stand in for an
+// absent one (flags bits 12..14 say which are real; the loads are unconditional and read index 0 then: a load inside a
+// branch makes the compiler wait for it, and with it for every load issued before, at the join); cp = the step control
 // block (sequence length of the KV append) or, for K slices, the epoch word of the tags — always a readable address.
 // Fields of the argument block that the tail of the kernel needs are touched right behind the vector loads (ZG_PIN):
 // the compiler issues a scalar load where a field is first used and waits for it on the spot, which put two to three
@@ -1605,15 +1607,13 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     const bool ln = prologue == PRO_LAYERNORM;
     const int n = tile * 16 + brow, nc = min(n, N - 1);
     const int m_out = (bq & 1) * 4 + wave, mc = min(m_out, M - 1);
-    float e_bias = 0.0f, e_c2 = 0.0f, e_res = 0.0f, e_g = 1.0f;
-    if (ln) {
-        e_c2 = e0[nc];
-        e_bias = e1[nc];  // c3 already holds the bias
-    } else {
-        if (e0) e_bias = e0[nc];
-        if (e1) e_res = e1[(size_t)mc * N + nc];
-        if (xg) e_g = xg[nc];
-    }
+    const int has_e0 = (int)((flags >> 12) & 1u), has_e1 = (int)((flags >> 13) & 1u), has_g = (int)((flags >> 14) & 1u);
+    // ln: (c2, c3 — which already holds the bias); otherwise (bias, residual); index 0 of the stand-in when absent
+    const float e0v = e0[nc * has_e0];
+    const float e1v = e1[ln ? nc : (mc * N + nc) * has_e1];
+    const float e_g = xg[nc * has_g];  // (behind a LayerNorm xg is x: any in-range element, unused)
+    const float e_c2 = e0v, e_res = ln ? 0.0f : e1v;
+    float e_bias = ln ? e1v : e0v;
     f32x4 xv[2][KP];  // LayerNorm statistics: this wave sums rows wave and wave + 4
     if (ln) {
 #pragma unroll
@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         const float out = epilogue_row(a, m_out, n, y, e_bias, e_res, T - 1, nobest);
         if (a.pl_out) {  // the next Linear reads this row as planes (of g * y when a LayerNorm follows)
             uint32_t hi, mid, lo;
-            split3_pk((!ln && xg) ? out * e_g : out, 0.0f, hi, mid, lo);
+            split3_pk(has_g ? out * e_g : out, 0.0f, hi, mid, lo);
             a.pl_out[plane_elem(0, m_out, n)] = (bf16_t)hi;
             a.pl_out[plane_elem(1, m_out, n)] = (bf16_t)mid;
             a.pl_out[plane_elem(2, m_out, n)] = (bf16_t)lo;
@@ -2032,10 +2032,14 @@ int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
     const bool ln = a.prologue == PRO_LAYERNORM;
     const int ksl = a.kslices == 4 ? 4 : 1;
     const unsigned nk = (unsigned)a.N | ((unsigned)(a.K / ksl) << 16);
-    const unsigned flags = (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8);
     const float* e0 = ln ? a.ln_c2 : a.bias;
     const float* e1 = ln ? a.ln_c3 : (a.epilogue == EPI_RESIDUAL ? a.resid : nullptr);
     const float* xg = ln ? a.x : (a.pl_out ? a.pl_g : nullptr);
+    const unsigned flags = (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8) | ((e0 ? 1u : 0u) << 12) |
+                           ((e1 ? 1u : 0u) << 13) | (((!ln && xg) ? 1u : 0u) << 14);
+    if (!e0) e0 = a.zero;
+    if (!e1) e1 = a.zero;
+    if (!xg) xg = a.zero;
     const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
     if (ksl == 4) {
         GemvArgs b = a;
