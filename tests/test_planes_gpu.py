@@ -1,7 +1,7 @@
 """Lock-step batch with bf16 weights: the activation planes between the kernels of a Block (GemvArgs.pl_in / pl_out,
 zg_common.h plane_elem), the four-wave plane-fed Linear, the attention-side head merge and the tagged hand-overs —
-against the CPU oracle, and against the paths they replace (ZGPT2_NO_PLANES / ZGPT2_NO_PL4 / ZGPT2_NO_TAGS switch them
-off per handle), which stay in the library as the route for shapes the new kernels do not take.
+against the CPU oracle, and against the paths they replace (ZGPT2_NO_PLANES / ZGPT2_NO_PL4 / ZGPT2_NO_TAGS /
+ZGPT2_NO_TILE_STATS switch them off per handle), which stay in the library as the route for shapes the new kernels do not take.
 
 Tolerance: greedy ids against independent oracle generations (golden_io.assert_greedy_ids_match: identical unless the
 oracle's own top-2 margin is inside the north_star bound); between the variants only the summation order of fp32 partial sums differs: 1e-5 of the logit scale, greedy ids identical."""
@@ -17,11 +17,12 @@ from zig_gpt2_amd.synth import GPTConfig
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {"default": {}, "tickets": {"ZGPT2_NO_TAGS": "1"}, "16-wave": {"ZGPT2_NO_PL4": "1"},
-            "16-wave tickets": {"ZGPT2_NO_PL4": "1", "ZGPT2_NO_TAGS": "1"}, "LDS planes": {"ZGPT2_NO_PLANES": "1"}}
+            "16-wave tickets": {"ZGPT2_NO_PL4": "1", "ZGPT2_NO_TAGS": "1"}, "LDS planes": {"ZGPT2_NO_PLANES": "1"},
+            "statistics from x": {"ZGPT2_NO_TILE_STATS": "1"}}
 
 
 def run_variant(monkeypatch, env, cfg, w, batch, prompts, n_steps, **kw):
-    for k in ("ZGPT2_NO_TAGS", "ZGPT2_NO_PL4", "ZGPT2_NO_PLANES"):
+    for k in ("ZGPT2_NO_TAGS", "ZGPT2_NO_PL4", "ZGPT2_NO_PLANES", "ZGPT2_NO_TILE_STATS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -66,6 +66,9 @@ struct zg_gpt {
     unsigned* epoch;
     unsigned long long *sk_tag, *part_tag;
     bool tags_on;
+    // LayerNorm statistics of x by 16-column tile, written by the producers of x (GemvArgs.st_out / st_in)
+    float* xst;
+    bool st_on;
     bool pl_on;
     int max_splits, lm_grid;
     // pinned host mirrors for small control traffic
@@ -171,6 +174,7 @@ void carve(zg_gpt* g, char* base) {
     g->ap = (bf16_t*)P(E * 48);
     g->attn_cnt = (int*)P(8 * c.n_heads * 4);
     g->epoch = (unsigned*)P(256);
+    g->xst = (float*)P(((E + 15) / 16) * 8 * 2 * 4);
     g->sk_tag = (unsigned long long*)P(((E + 15) / 16) * 4 * 128 * 8);
     g->part_tag = (unsigned long long*)P(8 * c.n_heads * g->max_splits * kPartStride * 8);
     g->sk_tiles = (int)((E + 15) / 16);
@@ -247,6 +251,7 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.pl_out = g->pl_on ? g->xp : nullptr;
     e.pl_g = g->layers[0].ln_1_g;
     e.epoch = (g->pl_on && g->tags_on && finish_only != 1 && finish_only != 2) ? g->epoch : nullptr;
+    e.st_out = g->st_on ? g->xst : nullptr;
     e.finish_only = finish_only;
     e.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
     return e;
@@ -360,6 +365,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.ln_c3 = y.c_attn_c3;
             a.epilogue = EPI_QKV;
             a.pl_in = g->pl_on ? g->xp : nullptr;
+            a.st_in = g->st_on ? g->xst : nullptr;
             a.q = g->q;
             a.k_cache = y.k_cache;
             a.v_cache = y.v_cache;
@@ -422,6 +428,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 a.pl_in = g->ap;
                 a.pl_out = g->xp;
                 a.pl_g = y.ln_2_g;
+                a.st_out = g->st_on ? g->xst : nullptr;
             }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 3));
@@ -440,6 +447,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.y = g->h4;
             a.y_stride = (int)(4 * E);
             if (g->pl_on) {  // gelu(c_fc) leaves as planes only
+                a.st_in = g->st_on ? g->xst : nullptr;
                 a.pl_in = g->xp;
                 a.pl_out = g->hp;
                 a.y = nullptr;
@@ -468,6 +476,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 if (l + 1 < g->cfg.n_layer) {  // the next Block's ln_1 + c_attn (ln_f + lm_head reads x itself)
                     a.pl_out = g->xp;
                     a.pl_g = g->layers[l + 1].ln_1_g;
+                    a.st_out = g->st_on ? g->xst : nullptr;
                 }
             }
             const int grid = gemv_plan(a, g->wt);
@@ -834,6 +843,29 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
                    gemv_planes_ok(a5, g->wt);
     }
     g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
+    g->st_on = false;
+    if (g->pl_on && !env_int("ZGPT2_NO_TILE_STATS", 0) && c.n_embed % 16 == 0 && c.n_embed / 16 <= 128) {
+        // every producer and consumer of x must be the four-wave kernel
+        const zg_layer& y = g->layers[0];
+        GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, 0);
+        a1.prologue = PRO_LAYERNORM;
+        a1.x_stride = (int)c.n_embed;
+        a1.ln_c2 = y.c_attn_c2;
+        a1.ln_c3 = y.c_attn_c3;
+        a1.epilogue = EPI_QKV;
+        GemvArgs a4 = a1;
+        a4.N = (int)(4 * c.n_embed);
+        a4.epilogue = EPI_GELU;
+        GemvArgs a3 = base_gemv(g, y.c_proj_w, y.c_proj_b, c.n_embed, c.n_embed, 0);
+        a3.prologue = PRO_NONE;
+        a3.epilogue = EPI_RESIDUAL;
+        a3.resid_stride = (int)c.n_embed;
+        GemvArgs a5 = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, c.n_embed, 4 * c.n_embed, 0);
+        a5.prologue = PRO_NONE;
+        a5.epilogue = EPI_RESIDUAL;
+        a5.resid_stride = (int)c.n_embed;
+        g->st_on = gemv_pl4_ok(a1, g->wt) && gemv_pl4_ok(a3, g->wt) && gemv_pl4_ok(a4, g->wt) && gemv_pl4_ok(a5, g->wt);
+    }
     if (g->lm_grid > 4096) {
         (void)hipFree(g->arena);
         delete g;

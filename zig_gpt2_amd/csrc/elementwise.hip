@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         }
         {   // the argument-block fields used behind the partial-maxima loads (zg_common.h ZG_PIN)
             ZG_PIN(a.forced); ZG_PIN(a.wte); ZG_PIN(a.wpe); ZG_PIN(a.weight_type); ZG_PIN(a.n_embed); ZG_PIN(a.cur_token); ZG_PIN(a.out_tokens);
-            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only);
+            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only); ZG_PIN(a.st_out);
         }
         if (b == 0 && a.progress != nullptr && a.finish_only == 0 && lane == 0) {
             // a step at sequence length s + 1 starts; block 0 of every launch of this queue lands on the XCD this block is on
@@ -235,6 +235,13 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
             *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(0, b, e)) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(1, b, e)) = u32x2{m0, m1};
             *reinterpret_cast<u32x2*>(a.pl_out + plane_elem(2, b, e)) = u32x2{l0, l1};
+        }
+        if (a.st_out) {  // LayerNorm statistics by 16-column tile: four consecutive threads hold one tile of one row
+            float s1 = (o.x + o.y) + (o.z + o.w);
+            float s2 = fmaf(o.x, o.x, fmaf(o.y, o.y, fmaf(o.z, o.z, o.w * o.w)));
+            s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+            s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+            if ((threadIdx.x & 3) == 0) *reinterpret_cast<float2*>(a.st_out + ((size_t)b * (a.n_embed >> 4) + (e >> 4)) * 2) = float2{s1, s2};
         }
     }
     if (threadIdx.x == 0 && a.epoch) *a.epoch += 1u;  // a step starts: new tags for its hand-overs

@@ -1614,8 +1614,21 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     const float e_g = xg[nc * has_g];  // (behind a LayerNorm xg is x: any in-range element, unused)
     const float e_c2 = e0v, e_res = ln ? 0.0f : e1v;
     float e_bias = ln ? e1v : e0v;
-    f32x4 xv[2][KP];  // LayerNorm statistics: this wave sums rows wave and wave + 4
-    if (ln) {
+    // LayerNorm statistics of rows wave and wave + 4 (the rows of this wave's outputs): from the producer's tile sums
+    // (flags bit 15: xg = st_in [8][K / 16][2]; lanes = tiles) or from x itself
+    const bool st_tiles = (flags >> 15) & 1u;
+    float2 sv[2][2];  // (no initialiser: a value that is either loaded or a constant makes the compiler wait for the load,
+                      // and every load before it, where the two paths join)
+    if (ln && st_tiles) {
+        const int ntl = K >> 4;  // <= 128
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                sv[j][t] = reinterpret_cast<const float2*>(xg)[(size_t)(wave + 4 * j) * ntl + min(lane + 64 * t, ntl - 1)];
+    }
+    f32x4 xv[2][KP];
+    if (ln && !st_tiles) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1624,6 +1637,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     }
     {   // the argument-block fields of the tail, fetched under the vector loads
         ZG_PIN(a.progress); ZG_PIN(a.pl_out); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
+        ZG_PIN(a.st_out);
         if (epilogue == EPI_QKV) {
             ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_f16);
         }
@@ -1670,7 +1684,22 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         }
     }
     ZG_STAMP(2);
-    if (ln) {
+    float st_mu = 0.0f, st_rs = 1.0f;  // st_tiles: statistics of row m_out, in registers
+    if (ln && st_tiles) {
+        const int ntl = K >> 4;
+        float t1[2], t2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            t1[j] = (lane < ntl ? sv[j][0].x : 0.0f) + (lane + 64 < ntl ? sv[j][1].x : 0.0f);
+            t2[j] = (lane < ntl ? sv[j][0].y : 0.0f) + (lane + 64 < ntl ? sv[j][1].y : 0.0f);
+            t1[j] = wave_allsum(t1[j]);
+            t2[j] = wave_allsum(t2[j]);
+        }
+        const float inv_k = 1.0f / (float)K;
+        const float s1 = (bq & 1) ? t1[1] : t1[0], s2 = (bq & 1) ? t2[1] : t2[0];
+        st_mu = s1 * inv_k;
+        st_rs = __builtin_amdgcn_rsqf(s2 * inv_k - st_mu * st_mu + a.eps);
+    } else if (ln) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = wave + 4 * j;
@@ -1697,6 +1726,9 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     __syncthreads();
     ZG_STAMP(4);
 
+    // The epilogue operands were loaded at entry; claim them here, while no store is in flight: vmcnt counts loads and
+    // stores in order, so a first use behind a store waits for that store's round trip as well.
+    asm volatile("" ::"v"(e0v), "v"(e1v), "v"(e_g));
     // ---- this wave's register of the tile: output (m_out, n) in lanes 0..31
     float y = 0.0f;
 #pragma unroll
@@ -1748,16 +1780,21 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         }
     }
     ZG_STAMP(5);
-    if (run && lane < 32 && n < N && m_out < M) {
+    float out = 0.0f;
+    const bool valid = run && lane < 32 && n < N && m_out < M;
+    if (valid) {
         if (ln) {  // y = r_m (S1 - mu_m c2_n) + c3_n
-            const float inv_k = 1.0f / (float)K;
-            const float mu = s_stat[m_out * 2] * inv_k;
-            const float rs = __builtin_amdgcn_rsqf(s_stat[m_out * 2 + 1] * inv_k - mu * mu + a.eps);
+            float mu = st_mu, rs = st_rs;
+            if (!st_tiles) {
+                const float inv_k = 1.0f / (float)K;
+                mu = s_stat[m_out * 2] * inv_k;
+                rs = __builtin_amdgcn_rsqf(s_stat[m_out * 2 + 1] * inv_k - mu * mu + a.eps);
+            }
             y = fmaf(rs, fmaf(-mu, e_c2, y), e_bias);
             e_bias = 0.0f;
         }
         Best nobest;
-        const float out = epilogue_row(a, m_out, n, y, e_bias, e_res, T - 1, nobest);
+        out = epilogue_row(a, m_out, n, y, e_bias, e_res, T - 1, nobest);
         if (a.pl_out) {  // the next Linear reads this row as planes (of g * y when a LayerNorm follows)
             uint32_t hi, mid, lo;
             split3_pk(has_g ? out * e_g : out, 0.0f, hi, mid, lo);
@@ -1765,6 +1802,11 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             a.pl_out[plane_elem(1, m_out, n)] = (bf16_t)mid;
             a.pl_out[plane_elem(2, m_out, n)] = (bf16_t)lo;
         }
+    }
+    if (a.st_out != nullptr && run) {  // tile sums of the rows written, for the LayerNorm of the next Linear (uniform branch)
+        const float v = valid ? out : 0.0f;
+        const float s1 = row16_allsum(v), s2 = row16_allsum(v * v);
+        if (lane < 32 && brow == 0 && m_out < M) *reinterpret_cast<float2*>(a.st_out + ((size_t)m_out * ((N + 15) >> 4) + tile) * 2) = float2{s1, s2};
     }
     ZG_STAMP(6);
     ZG_STAMP(7);
@@ -2021,6 +2063,7 @@ inline int pl4_pairs(const GemvArgs& a) {
     const int off = getenv("ZGPT2_NO_PL4") ? atoi(getenv("ZGPT2_NO_PL4")) : 0;  // read per call: tests flip it between handles
     if (off || a.pl_in == nullptr || a.epilogue == EPI_ARGMAX || a.rows_per_wave != 1) return 0;
     if (a.N > 0xffff || (a.prologue == PRO_LAYERNORM && a.x_stride != a.K) || (a.epilogue == EPI_RESIDUAL && a.resid_stride != a.N)) return 0;
+    if (a.st_in != nullptr && a.K / 16 > 128) return 0;
     const int ksl = a.kslices > 1 ? a.kslices : 1;
     if (a.K % (64 * ksl) != 0) return 0;
     const int kp = (a.K / ksl / 64 + 3) / 4;
@@ -2034,9 +2077,9 @@ int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
     const unsigned nk = (unsigned)a.N | ((unsigned)(a.K / ksl) << 16);
     const float* e0 = ln ? a.ln_c2 : a.bias;
     const float* e1 = ln ? a.ln_c3 : (a.epilogue == EPI_RESIDUAL ? a.resid : nullptr);
-    const float* xg = ln ? a.x : (a.pl_out ? a.pl_g : nullptr);
+    const float* xg = ln ? (a.st_in ? a.st_in : a.x) : (a.pl_out ? a.pl_g : nullptr);
     const unsigned flags = (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8) | ((e0 ? 1u : 0u) << 12) |
-                           ((e1 ? 1u : 0u) << 13) | (((!ln && xg) ? 1u : 0u) << 14);
+                           ((e1 ? 1u : 0u) << 13) | (((!ln && xg) ? 1u : 0u) << 14) | (((ln && a.st_in) ? 1u : 0u) << 15);
     if (!e0) e0 = a.zero;
     if (!e1) e1 = a.zero;
     if (!xg) xg = a.zero;
@@ -2273,6 +2316,14 @@ int gemv_rows_per_wg(const GemvArgs& a, int weight_type) {
 bool gemv_planes_ok(const GemvArgs& a, int weight_type) {
     if (a.epilogue == EPI_ARGMAX || !gemv_use_mfma(a, weight_type)) return false;
     return a.prologue == PRO_NONE || (a.prologue == PRO_LAYERNORM && a.ln_c2 != nullptr && a.ln_c3 != nullptr && a.K <= 2048);
+}
+
+bool gemv_pl4_ok(const GemvArgs& a, int weight_type) {
+    if (!gemv_planes_ok(a, weight_type)) return false;
+    GemvArgs b = a;
+    (void)gemv_plan(b, weight_type);
+    if (b.pl_in == nullptr) b.pl_in = reinterpret_cast<const bf16_t*>(a.W);  // any non-null: only the shape is judged
+    return pl4_pairs(b) > 0;
 }
 
 bool gemv_planes_producer_ok(const GemvArgs& a, int weight_type) { return a.epilogue != EPI_ARGMAX && gemv_use_mfma(a, weight_type); }

@@ -82,6 +82,11 @@ struct GemvArgs {
     const unsigned* epoch;
     unsigned launch_id;
     unsigned long long* sk_tag;
+    // LayerNorm statistics by tile: a producer of x (four-wave plane-fed kernel, embed kernel) also writes, per 16-column tile
+    // and batch row, the sum and the sum of squares of its 16 outputs, st_out [8][N / 16][2]; the LayerNorm-fed consumer
+    // adds the tiles (st_in) instead of reading x again — a third of its vector-memory traffic
+    float* st_out;
+    const float* st_in;
     const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
     unsigned* progress;       // launch counter followed by the side-stream prefetcher (prefetch.hip); null = not counted
@@ -93,6 +98,8 @@ bool gemv_supported(const GemvArgs& a, int weight_type);
 bool gemv_planes_ok(const GemvArgs& a, int weight_type);
 // ... and whether it can write its output rows as planes (GemvArgs.pl_out).
 bool gemv_planes_producer_ok(const GemvArgs& a, int weight_type);
+// Whether a planned plane-fed launch runs as the four-wave kernel (the one that writes / reads the tile statistics).
+bool gemv_pl4_ok(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int gemv_kslices(const GemvArgs& a);
@@ -229,6 +236,7 @@ struct EmbedArgs {
     bf16_t* pl_out;          // optional planes of pl_g * x for the first Linear of the lock-step batch (GemvArgs.pl_in)
     const float* pl_g;
     unsigned* epoch;         // optional step counter behind the tagged hand-overs (GemvArgs.sk_tag): +1 when a step starts
+    float* st_out;           // optional LayerNorm statistics by tile of x (GemvArgs.st_in): [8][n_embed / 16][2]
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
     unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
 };
