@@ -181,8 +181,23 @@ __device__ __forceinline__ void read_b_all(bf16x8 (&fb)[4][NT], const unsigned (
 template <int NT, bool GELU, bool OUT_BF16, int ABL>
 __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, void* __restrict__ C, int M, int N,
-                                                         GemmPlanes pl, int ldc, int tiles_m, int tiles_n, int gw, int dbg) {
+                                                         unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+    // All 14 dwords of the arguments are preloaded into SGPRs at wave launch (zg_common.h ZG_PIN): the first version passed the
+    // plane description and the tile counts behind them and began with a scalar round trip to the kernarg segment — cold for
+    // every launch — before its first DMA.  p0 = lda | ldb << 16; p1 = ldc | K-steps per plane << 20 | plane pairs << 28;
+    // p2 = A plane of pair i in bits [2i, 2i + 2) | B planes << 12 | band width << 24; p3 = workgroups | dbg << 10.
     using P = S4<NT>;
+    GemmPlanes pl;
+    pl.lda = (int)(p0 & 0xffffu);
+    pl.ldb = (int)(p0 >> 16);
+    const int ldc = (int)(p1 & 0xfffffu);
+    pl.kpp = (int)((p1 >> 20) & 0xffu);
+    pl.npairs = (int)(p1 >> 28);
+    pl.pa_bits = p2 & 0xfffu;
+    pl.pb_bits = (p2 >> 12) & 0xfffu;
+    const int gw = (int)(p2 >> 24);
+    const int dbg = (int)(p3 >> 10);
+    const int tiles_m = (M + 255) >> 8, tiles_n = (N + P::BN - 1) / P::BN;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)lds;
 
     // ---- this workgroup's tiles: XCD x = bid % 8 owns a contiguous range of the banded order
-    const int n_tiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
+    const int n_tiles = tiles_m * tiles_n, G = (int)(p3 & 0x3ffu), bid = blockIdx.x;
     const int nx = G < 8 ? G : 8;
     const int xcd = bid % nx, loc = bid / nx;
     const int gx = G / nx + (xcd < G % nx ? 1 : 0);
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         }
         const bool in_cur = pi < pl.npairs;
         if (!in_cur) pi = 0;
-        const unsigned pa = (pl.pa_bits >> (4 * pi)) & 15u, pb = (pl.pb_bits >> (4 * pi)) & 15u;
+        const unsigned pa = (pl.pa_bits >> (2 * pi)) & 3u, pb = (pl.pb_bits >> (2 * pi)) & 3u;
         Ahead s;
         s.kbA = (pa * (unsigned)kpp + (unsigned)kk) * 128u;
         s.kbB = (pb * (unsigned)kpp + (unsigned)kk) * 128u;
@@ -688,8 +703,18 @@ int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, 
     const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;  // tests: few workgroups, many tiles each
     const int cus = cus_env > 0 ? cus_env : 256;
     const int grid = n_tiles < cus ? n_tiles : cus;
-    hipLaunchKernelGGL((gemm_s4_kernel<NT, GELU, OUT_BF16, ABL>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N, pl, ldc,
-                       tiles_m, tiles_n, gw, getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
+    const unsigned dbg = (unsigned)(getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
+    ZG_REQUIRE(pl.lda > 0 && pl.ldb > 0 && pl.lda < 65536 && pl.ldb < 65536 && ldc < (1 << 20) && pl.kpp < 256 && pl.npairs <= 6 && gw < 256 &&
+                   grid < 1024 && dbg < (1u << 22),
+               ZG_ERR_UNSUPPORTED, "gemm: lda %d / ldb %d / ldc %d / K beyond the packed kernel arguments", pl.lda, pl.ldb, ldc);
+    unsigned pa2 = 0, pb2 = 0;
+    for (int i = 0; i < pl.npairs; ++i) {
+        pa2 |= ((pl.pa_bits >> (4 * i)) & 3u) << (2 * i);
+        pb2 |= ((pl.pb_bits >> (4 * i)) & 3u) << (2 * i);
+    }
+    hipLaunchKernelGGL((gemm_s4_kernel<NT, GELU, OUT_BF16, ABL>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
+                       (unsigned)pl.lda | ((unsigned)pl.ldb << 16), (unsigned)ldc | ((unsigned)pl.kpp << 20) | ((unsigned)pl.npairs << 28),
+                       pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10));
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
