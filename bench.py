@@ -12,6 +12,7 @@ from rank 0 over RCCL, no collective in the timed region).  Weights/prompts are 
 PRNG, bf16-representable) — there are no checkpoints offline.  One JSON line is printed by rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -302,18 +303,18 @@ def main():
         os.environ["ZGPT2_TIME_CYCLE"] = "1"  # walk the layers: weights / KV from the memory side, as in the real step
         us_cold, _ = model.time_kernel(which, 256)
         os.environ["ZGPT2_TIME_CYCLE"] = "0"
-        table.append({"class": name, "launches_per_token": n_launch, "avg_launch_us": round(us, 3),
+        sym = C.create_string_buffer(160)
+        _lib.check(lib.zg_debug_last_kernel(sym, 160))
+        table.append({"class": name, "_symbol": sym.value.decode(), "launches_per_token": n_launch, "avg_launch_us": round(us, 3),
                       "avg_launch_us_layers_walked": round(us_cold, 3),
                       "algorithmic_bytes_per_launch": int(nbytes), "GBps": round(nbytes / us / 1e3, 1),
                       "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_token": round(us * n_launch, 2)})
     tot_us = sum(r["us_per_token"] for r in table)
     for r in table:
         r["share_of_token_time"] = round(r["us_per_token"] / tot_us, 4)
-    sym1 = {1: "gemv_lnk_kernel", 2: "attn_decode_h8_kernel" if a.kv_f16 else "attn_decode_kernel<float>", 3: "gemv_kernel (PRO_ATTN_MERGE)",
-            4: "gemv_lnk_kernel", 5: "gemv_ksplit_kernel", 6: "gemv_kernel (ARGMAX)"}
-    symn = {1: "gemv_mfma_kernel", 2: sym1[2], 3: "gemv_mfma_kernel", 4: "gemv_mfma_kernel", 5: "gemv_mfma_kernel (KSL = 4)", 6: "lm_head_wpt_kernel"}
-    for r, (which, _, _, _) in zip(table, classes):
-        r["kernel_symbol"] = (sym1 if ppg == 1 else symn)[which]
+    # the kernel instantiation behind every class, as noted by the library's launchers while the chain above was recorded
+    for r in table:
+        r["kernel_symbol"] = r.pop("_symbol")
     dom = max(table, key=lambda r: r["us_per_token"])
     lm = table[-1]
     n_prof = min(64, ctx)

@@ -136,6 +136,9 @@ unsigned long long zg_debug_gemm_launches(void);
 /* Diagnostic: shader-clock stamps {count, start, end} of workgroup 0 / wave 0 of the last GEMM launched with
  * ZGPT2_GEMM_DBG bit 256 (tools/microbench/gemm_bench.cpp: cycles vs wall time = the clock the chip ran at). */
 int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words);
+/* Diagnostic: name of the kernel instantiation the last decode-kernel launcher of this thread picked (launches recorded
+ * into a graph count; bench.py reports it as the symbol of the roofline kernel). */
+int zg_debug_last_kernel(char* out, size_t n);
 int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len);
 
 /* ------------------------------------------------------------------ model tier: src/main.zig */

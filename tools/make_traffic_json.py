@@ -22,11 +22,11 @@ CLASSES = {
         "ln_f + lm_head + argmax": r"gemv_kernel<unsigned short, 1, 16, 6, true>",
     }),
     "124M/8/bf16": ("124m_8prompts", {
-        "ln_1 + c_attn + KV append": r"gemv_mfma_kernel<2, 16, false, 1",
+        "ln_1 + c_attn + KV append": r"gemv_pl4_kernel<3, 1>",
         "attention (split-KV decode)": r"attn_decode_kernel<float>",
-        "head merge + attn c_proj + residual": r"gemv_mfma_kernel<2, 16, false, 1",
-        "ln_2 + c_fc + GELU": r"gemv_mfma_kernel<2, 16, false, 1",
-        "mlp c_proj + residual": r"gemv_mfma_kernel<\d+, 16, false, 4",
+        "head merge + attn c_proj + residual": r"gemv_pl4_kernel<3, 1>",
+        "ln_2 + c_fc + GELU": r"gemv_pl4_kernel<3, 1>",
+        "mlp c_proj + residual": r"gemv_pl4_kernel<3, 4>",
         "ln_f + lm_head + argmax": r"lm_head_wpt_kernel",
     }),
     "xl/1/bf16": ("xl", {

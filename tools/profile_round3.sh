@@ -55,6 +55,14 @@ for k in s4 p8; do
 done
 tools/bin/gemm_bench -k s4 > $out/${tag}_gemm_bench.txt 2>&1; tools/bin/gemm_bench -k p8 -nocheck >> $out/${tag}_gemm_bench.txt 2>&1
 tools/bin/mfma_lds > $out/${tag}_mfma_lds.txt 2>&1; tools/bin/dma_intake > $out/${tag}_dma_intake.txt 2>&1
+for a in "256 768 2000 256" "256 3072 2000 256" "64 768 2000 256"; do tools/bin/persistent_chain $a | tail -1; done > $out/${tag}_persistent_chain.txt 2>&1
+# 4b. lock-step batch: planes / tagged hand-overs on and off, and the in-kernel timelines (stamps build)
+python tools/planes_ab.py 124M:8 124M:3 2> /dev/null > $out/${tag}_planes_ab.jsonl
+AB_KV_F16=1 python tools/planes_ab.py 124M:8 2> /dev/null >> $out/${tag}_planes_ab.jsonl
+if [ -f zig_gpt2_amd/lib/libzgpt2_hip_stamps.so ]; then
+  ZGPT2_LIB=zig_gpt2_amd/lib/libzgpt2_hip_stamps.so python tools/kernel_stamps.py 124M 1 2> /dev/null > $out/${tag}_kernel_stamps_1prompt.txt
+  ZGPT2_LIB=zig_gpt2_amd/lib/libzgpt2_hip_stamps.so python tools/kernel_stamps.py 124M 8 2> /dev/null > $out/${tag}_kernel_stamps_8prompts.txt
+fi
 # 5. whole-prompt prefill: timings and kernel trace at 1023 prompt tokens
 python tools/bench_prefill.py > $out/${tag}_prefill.jsonl 2> $out/prefill.err
 python tools/bench_prefill.py --batch 8 --lengths 128,1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err

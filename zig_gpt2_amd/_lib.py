@@ -45,6 +45,7 @@ SIGNATURES = {
     "zg_unregister_all": (C.c_int, []),
     "zg_debug_gemm_launches": (C.c_ulonglong, []),
     "zg_debug_gemm_stamps": (C.c_int, [vp, sz]),
+    "zg_debug_last_kernel": (C.c_int, [C.c_char_p, sz]),
     "zg_linear_forward": (C.c_int, [sz, sz, vp, vp, vp, sz, vp, sz]),
     "zg_embedding_forward": (C.c_int, [sz, vp, sz, vp, sz, vp, sz]),
     "zg_layernorm_forward": (C.c_int, [sz, vp, vp, C.c_float, vp, sz]),

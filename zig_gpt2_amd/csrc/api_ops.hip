@@ -18,6 +18,14 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+void note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
     (void)hipGetLastError();
@@ -368,6 +376,11 @@ int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_n
 
 unsigned long long zg_debug_gemm_launches(void) { return gemm_mfma_launch_count(); }
 int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words) { return gemm_s4_stamps(out, n_words); }
+int zg_debug_last_kernel(char* out, size_t n) {
+    if (!out || n == 0) return ZG_ERR_ARG;
+    snprintf(out, n, "%s", zg::g_kernel);
+    return ZG_OK;
+}
 
 int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len) {
     ZG_TRY(require_init());

@@ -520,6 +520,7 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     const int* cw = a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(ctx().d_zero);
     const unsigned* ew = a.epoch ? a.epoch : reinterpret_cast<const unsigned*>(ctx().d_zero);
     static const bool h8_off = getenv("ZGPT2_NO_KV_H8") != nullptr;  // A/B: the fp16 cache on the fp32 lane map (8-byte loads)
+    note_kernel((a.kv_f16 && a.stride_t == 64 && !h8_off) ? "attn_decode_h8_kernel" : (a.kv_f16 ? "attn_decode_kernel<_Float16>" : "attn_decode_kernel<float>"));
     if (a.kv_f16 && a.stride_t == 64 && !h8_off)
         hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     else if (a.kv_f16)

@@ -676,6 +676,8 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
     // attention partials and their split stride, bias and residual (a few zero floats when absent: read at index 0)
     const int epilogue = (int)(em & 0xffu), merge_splits = (int)((em >> 8) & 0xffu);
     const int has_bias = (int)((em >> 16) & 1u), has_resid = (int)((em >> 17) & 1u);
+    ZG_STAMP_DECL();
+    ZG_STAMP(0);
     // merge_splits > 0 (attn c_proj): the input is the head merge of the attention partials — every lane combines
     // the <= 4 split partials of ITS OWN 8-element chunks (a chunk lies inside one head), all loads issued with the
     // weights; no shared strip, no barrier in front of the FMAs (the merge through an LDS strip cost 3.9 us per
@@ -744,9 +746,11 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
         bias_n = bias[n * has_bias];
         resid_n = resid[n * has_resid];
     }
+    ZG_STAMP(1);
     ZG_PIN(a.y);  // the tail's argument-block fields, fetched under the vector loads (zg_common.h ZG_PIN)
     ZG_PIN(a.progress);
     pf_count(a.progress);
+    ZG_STAMP(2);
 #pragma unroll
     for (int i = 0; i < CPL; ++i)
         if (lr + LPR * i >= nchq) xr[i] = zero_w8();  // clamped surplus chunks multiply zeros
@@ -765,16 +769,22 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
     float sp[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) sp[p] = dot(wq[p]);
+    ZG_STAMP(3);
     if (lr == 0) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) part[wave][p * RPP + rsub] = sp[p];
     }
     __syncthreads();
+    ZG_STAMP(4);
     if (tid < ROWS && row0 + tid < N) {
         const int n = row0 + tid;
         const float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + bias_n;
         a.y[n] = epilogue == EPI_RESIDUAL ? v + resid_n : (epilogue == EPI_GELU ? gelu_ref(v) : v);
     }
+    ZG_STAMP(5);
+    ZG_STAMP(6);
+    ZG_STAMP(7);
+    ZG_STAMP_FLUSH();
 }
 
 template <typename WT>
@@ -787,6 +797,7 @@ int launch_ksplit(const GemvArgs& a, hipStream_t s) {
 #define ZG_KS(LPR_, CPL_)                                                                                                \
     {                                                                                                                    \
         constexpr int rows = 2 * (64 / LPR_);                                                                            \
+        note_kernel("gemv_ksplit_kernel<%s, %d, %d, 2>", sizeof(WT) == 2 ? "unsigned short" : "float", LPR_, CPL_);         \
         hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_, 2>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
                            a.N, a.K, em, a.part ? a.part : a.zero, a.max_splits, a.bias ? a.bias : a.zero,              \
                            has_resid ? a.resid : a.zero, a);                                                             \
@@ -836,6 +847,8 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
     // 14 preloaded dwords: Wv, xin, ne = N | epilogue << 24, K, ln_g, c2, c3, cw = the step control block (always a
     // readable address: its second word is the sequence length of the KV append)
     const int N = (int)(ne & 0xffffffu), epilogue = (int)(ne >> 24);
+    ZG_STAMP_DECL();
+    ZG_STAMP(0);
     constexpr int RPP = 64 / LPR, ROWS = NP * RPP;
     __shared__ float part[4][ROWS];
     __shared__ float stat[4][2];
@@ -877,6 +890,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         c3n = c3[n];
     }
     const int T = max(cw[1], 1);  // KV append position (EPI_QKV)
+    ZG_STAMP(1);
     {   // the argument-block fields of the tail, fetched under the vector loads (zg_common.h ZG_PIN)
         ZG_PIN(a.progress); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
         if (epilogue == EPI_QKV) {
@@ -884,6 +898,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         }
     }
     pf_count(a.progress);
+    ZG_STAMP(2);
     // statistics of this wave's quarter (every LPR-lane group holds the whole quarter) and z = g x
     float sx = 0.0f, sxx = 0.0f;
 #pragma unroll
@@ -913,6 +928,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
     float sp[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) sp[p] = dot(wq[p]);
+    ZG_STAMP(3);
     if (lr == 0) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) part[wave][p * RPP + rsub] = sp[p];
@@ -922,6 +938,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         stat[wave][1] = sxx;
     }
     __syncthreads();
+    ZG_STAMP(4);
     if (tid < ROWS && row0 + tid < N) {
         const int n = row0 + tid;
         const float inv_k = 1.0f / (float)K;
@@ -933,6 +950,10 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         Best nobest;
         epilogue_row(a, 0, n, y, 0.0f, 0.0f, T - 1, nobest);
     }
+    ZG_STAMP(5);
+    ZG_STAMP(6);
+    ZG_STAMP(7);
+    ZG_STAMP_FLUSH();
 }
 
 // c2[n] = sum_k W[n][k] g[k], c3[n] = sum_k W[n][k] b[k] + bias[n]: one wave per row, fp32 accumulation.
@@ -966,6 +987,7 @@ int launch_lnk(const GemvArgs& a, hipStream_t s) {
 #define ZG_LK(LPR_, CPL_)                                                                                              \
     {                                                                                                                  \
         constexpr int rows = 4 * (64 / LPR_);                                                                          \
+        note_kernel("gemv_lnk_kernel<%s, %d, %d, 4>", sizeof(WT) == 2 ? "unsigned short" : "float", LPR_, CPL_);          \
         hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_, 4>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
                            (unsigned)a.N | ((unsigned)a.epilogue << 24), a.K, a.ln_g, a.ln_c2, a.ln_c3,                 \
                            a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a);   \
@@ -2003,6 +2025,7 @@ int launch_lm_wpt(const GemvArgs& a, int grid, hipStream_t s) {
             raised = true;
         }
     }
+    note_kernel("lm_head_wpt_kernel<%d>", NS);
     hipLaunchKernelGGL((lm_head_wpt_kernel<NS>), dim3(grid), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K,
                        a.M, a.rows_per_wave, a.ln_g, a.ln_b, a);
     ZG_HIP(hipGetLastError());
@@ -2037,6 +2060,7 @@ int launch_mfma_inst2(const GemvArgs& a, int grid, bool alias, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = true;
     }
+    note_kernel("gemv_mfma_kernel<%d, %d, %s, %d, %s, %s>", KS, NW, ARGMAX ? "true" : "false", KSL, LINE ? "true" : "false", GPL ? "true" : "false");
     hipLaunchKernelGGL((gemv_mfma_kernel<KS, NW, ARGMAX, KSL, LINE, GPL>), dim3(grid, KSL), dim3(NW * 64), lds, s,
                        reinterpret_cast<const bf16_t*>(a.W), a.x, a.N, a.K / KSL, a.M, a.rows_per_wave, a.prologue,
                        a.epilogue, a.ln_g, a.ln_b, b);
@@ -2074,6 +2098,7 @@ template <int KP>
 int launch_pl4(const GemvArgs& a, int grid, hipStream_t s) {
     const bool ln = a.prologue == PRO_LAYERNORM;
     const int ksl = a.kslices == 4 ? 4 : 1;
+    note_kernel("gemv_pl4_kernel<%d, %d>", KP, ksl);
     const unsigned nk = (unsigned)a.N | ((unsigned)(a.K / ksl) << 16);
     const float* e0 = ln ? a.ln_c2 : a.bias;
     const float* e1 = ln ? a.ln_c3 : (a.epilogue == EPI_RESIDUAL ? a.resid : nullptr);
@@ -2145,6 +2170,7 @@ int launch_inst(const GemvArgs& a, int grid, hipStream_t s) {
         }
     }
     ZG_REQUIRE(lds <= 160 * 1024, ZG_ERR_UNSUPPORTED, "gemv: M=%d x K=%d does not fit LDS", a.M, a.K);
+    note_kernel("gemv_kernel<%s, %d, %d, %d, %s>", sizeof(WT) == 2 ? "unsigned short" : "float", MT, LPR, CPL, ARGMAX ? "true" : "false");
     hipLaunchKernelGGL((gemv_kernel<WT, MT, LPR, CPL, ARGMAX>), dim3(grid), dim3(64 * wpw), lds, s, a.W, a.x, a.N, a.K,
                        (unsigned)a.M | ((unsigned)a.prologue << 4) | ((unsigned)a.epilogue << 8) | ((unsigned)wpw << 12), a.rows_per_wave,
                        a.ln_g, a.ln_b, a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a);

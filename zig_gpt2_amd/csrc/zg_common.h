@@ -10,6 +10,9 @@ namespace zg {
 
 // ------------------------------------------------------------------------------ error plumbing
 void set_error(const char* fmt, ...);
+// Diagnostic: the launchers of the decode kernels note the instantiation they picked (zg_debug_last_kernel; bench.py quotes
+// it as the roofline's kernel symbol instead of a hand-kept table).
+void note_kernel(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define ZG_HIP(expr)                                                         \
