@@ -345,9 +345,12 @@ int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
 // One decode step = GPT.forward (main.zig:178-195) for all sequences.
 // `only` >= 0 (measurement): launch just that kernel class of layer `only_layer`.
 // rec != nullptr: nothing is launched; the step's launches are described for the prefetcher instead (emit_gemv).
+// salt >= 0 (measurement chains of one kernel class): launch ids of the tagged hand-overs by chain position instead of by
+// layer, so that consecutive launches of the chain never find each other's tags.
 int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1, size_t only_layer = 0,
-                 std::vector<PfJob>* rec = nullptr) {
+                 std::vector<PfJob>* rec = nullptr, int salt = -1) {
     const size_t E = g->cfg.n_embed;
+    auto launch_id = [&](size_t l, int k) { return (unsigned)(salt >= 0 ? 1 + (2 * salt + k) % 254 : 2 * (int)l + 1 + k); };
     ZG_TRY(prof_mark(prof, -1, s));
     if (rec) rec->push_back(PfJob{});
     else if (only < 0 || only == 0) ZG_TRY(launch_embed_step(embed_args(g, only == 0 ? 3 : 0), s));  // main.zig:179-183
@@ -393,9 +396,9 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             if (g->pl_on) {
                 a.pl_out = g->ap;
                 a.merge_cnt = g->attn_cnt;
-                if (g->tags_on && 2 * l + 1 <= 255) {
+                if (g->tags_on && 2 * l + 2 <= 255) {
                     a.epoch = g->epoch;
-                    a.launch_id = (unsigned)(2 * l + 1);
+                    a.launch_id = launch_id(l, 0);
                     a.part_tag = g->part_tag;
                 }
             }
@@ -469,7 +472,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             if (g->pl_on) {
                 if (g->tags_on && 2 * l + 2 <= 255) {
                     a.epoch = g->epoch;
-                    a.launch_id = (unsigned)(2 * l + 2);
+                    a.launch_id = launch_id(l, 1);
                     a.sk_tag = g->sk_tag;
                 }
                 a.pl_in = g->hp;
@@ -1285,8 +1288,11 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     int st = ZG_OK;
     // ZGPT2_TIME_CYCLE=1 (measurement): walk the layers, so that no launch finds its weights in the L2s
     const bool cycle = getenv("ZGPT2_TIME_CYCLE") && atoi(getenv("ZGPT2_TIME_CYCLE")) != 0;
+    // tagged hand-overs: a new epoch per replay and a launch id per chain position, so that every merging split / slice
+    // waits for ITS writers as in a real step (one more tiny launch per 64)
+    if (g->tags_on && which != 0) st = launch_epoch_bump(g->epoch, s);
     for (int i = 0; i < chain && st == ZG_OK; ++i)
-        st = enqueue_step(g, true, bucket_t_hi(g, T), s, nullptr, which, cycle ? (size_t)i % g->cfg.n_layer : 0);
+        st = enqueue_step(g, true, bucket_t_hi(g, T), s, nullptr, which, cycle ? (size_t)i % g->cfg.n_layer : 0, nullptr, i);
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (st != ZG_OK) return st;
     ZG_HIP(ce);

@@ -332,6 +332,13 @@ int launch_softmax(float* x, size_t n, hipStream_t s) {
     return ZG_OK;
 }
 
+__global__ void epoch_bump_kernel(unsigned* epoch) { *epoch += 1u; }
+int launch_epoch_bump(unsigned* epoch, hipStream_t s) {
+    hipLaunchKernelGGL(epoch_bump_kernel, dim3(1), dim3(1), 0, s, epoch);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int launch_embedding(const float* w, size_t emb_dim, const size_t* idx, size_t n_idx, size_t n_rows,
                      float* out, int* d_oob, hipStream_t s) {
     if (n_idx == 0) return ZG_OK;

@@ -139,6 +139,7 @@ int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, i
                       int seq_len, float* out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ elementwise
+int launch_epoch_bump(unsigned* epoch, hipStream_t s);  // measurement chains: advance the tag epoch (api_gpt.hip zg_gpt_time_kernel)
 int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s);
 int launch_gelu(float* x, size_t n, hipStream_t s);
 int launch_softmax(float* x, size_t n, hipStream_t s);
