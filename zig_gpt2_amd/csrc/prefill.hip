@@ -160,14 +160,15 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 // A: [M][3K] bf16 (hi | mid | lo), B: [N][K] bf16, bias [N].  C: fp32 [M][ldc] (PF_F32, PF_RESID) or bf16
 // [M][3N] split planes (PF_GELU_SPLIT).  N % 64 == 0, K % 64 == 0, any M.
-template <int EPI, int NS>  // NS 64-column strips per wave: the tile is 128 x (128 NS)
+template <int EPI, int NS, int NSPL = kSplit>  // NS 64-column strips per wave: the tile is 128 x (128 NS); NSPL activation planes multiplied
 __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                               const float* __restrict__ bias, void* __restrict__ C, int M,
                                                               int N, int K, int ldc, unsigned tp, int n_tiles,
                                                               const PrefillQkv qa) {
     // tp = tiles_n | split-K slices << 12 | activation planes << 24: the 14 preloaded argument dwords carry everything the
     // first DMA depends on (zg_common.h ZG_PIN; gridDim is a scalar load from the kernarg segment)
-    const int tiles_n = (int)(tp & 0xfffu), nsplit = (int)(tp >> 24);
+    const int tiles_n = (int)(tp & 0xfffu);
+    constexpr int nsplit = NSPL;
     // nsplit = activation planes multiplied: 3 = exact fp32 activations (hi + mid + lo), 2 = hi + mid only
     // (2^-17 relative per activation, ~2e-5 of the logit scale end to end: inside north_star's 1e-3, outside the
     // strict near-zero floor of the tests; 2/3 of the matrix work)
@@ -215,23 +216,54 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
         __builtin_amdgcn_s_barrier();        // everyone's did, and nobody still reads the other slot
         if (t + 1 < nt) issue(t + 1);
         const char* cur = lds + ((t - t0) & 1) * kStageB;
+        // 12 groups (16-k slice kk, plane p = 2, 1, 0: smallest plane first) of 2 NJ MFMAs.  The fragments of group g + 1 are
+        // read IN FRONT of group g's MFMAs (two register sets, sched barriers pin the order): with one wave per SIMD nothing
+        // else covers the LDS latency — the first version read a group's fragments, waited, multiplied, and spent as long
+        // waiting as multiplying.  Only the first group of a K-step is exposed (its data arrives with the barrier above).
+        // (The plane count is a template parameter: a run-time test around the MFMAs made the compiler wait for ALL LDS reads —
+        // the prefetched ones included — in front of every group.)
+        // The reads are hand-issued (asm) with COUNTED waits: left to itself the compiler waits for lgkmcnt(0) in front of
+        // every second group, i.e. also for the reads it has just issued for the group after.
+        bf16x8 bq[2][NJ], aq[2][2];
+        const unsigned cur_a = (unsigned)(unsigned long)(lds_ptr_t)cur;
+        auto rd = [&](bf16x8& dst, unsigned tile_off, int row, int chunk) {
+            const unsigned addr = cur_a + tile_off + (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+        };
+        auto rd_b = [&](int kk, bf16x8(&b)[NJ]) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 b[NJ];
+            for (int j = 0; j < NJ; ++j) rd(b[j], 0u, wn * 64 * NS + j * 32 + frow, kk * 2 + fk);
+        };
+        auto rd_a = [&](int kk, int p, bf16x8(&a)[2]) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = read_frag(cur, wn * 64 * NS + j * 32 + frow, kk * 2 + fk);
+            for (int i = 0; i < 2; ++i) rd(a[i], (unsigned)(kBBytes + p * kTileBytes), wm * 64 + i * 32 + frow, kk * 2 + fk);
+        };
+        rd_b(0, bq[0]);
+        rd_a(0, NSPL - 1, aq[0]);
 #pragma unroll
-            for (int p = kSplit - 1; p >= 0; --p) {  // smallest plane first
-                if (p >= nsplit) continue;
-                bf16x8 a[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = read_frag(cur + kBBytes + p * kTileBytes, wm * 64 + i * 32 + frow, kk * 2 + fk);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int g = 0; g < 4 * NSPL; ++g) {
+            const int kk = g / NSPL;
+            int n_next = 0;  // reads issued for group g + 1: still in flight when group g multiplies
+            if (g + 1 < 4 * NSPL) {
+                const int kk1 = (g + 1) / NSPL, p1 = NSPL - 1 - (g + 1) % NSPL;
+                if (kk1 != kk) {
+                    rd_b(kk1, bq[kk1 & 1]);
+                    n_next += NJ;
+                }
+                rd_a(kk1, p1, aq[(g + 1) & 1]);
+                n_next += 2;
             }
+            if (n_next == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (n_next == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (n_next == 2 + NJ && NJ == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[g & 1][i], bq[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
@@ -359,14 +391,15 @@ __global__ __launch_bounds__(256) void prefill_reduce_resid_ln_kernel(const floa
     }
 }
 
-template <int EPI, int NS>
-int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
-                           float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, int nsplit, hipStream_t s) {
+template <int EPI, int NS, int NSPL>
+int launch_prefill_gemm_np(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                           float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, hipStream_t s) {
+    constexpr int nsplit = NSPL;
     static bool raised = false;
     if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI, NS>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<EPI, NS, NSPL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(NS)));
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<PF_PARTIAL, NS>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_kernel<PF_PARTIAL, NS, NSPL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(NS)));
         raised = true;
     }
@@ -381,10 +414,10 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
     static const int force = getenv("ZGPT2_PF_SPLITK") ? atoi(getenv("ZGPT2_PF_SPLITK")) : 0;
     if (force > 0) n_sp = force;
     if (n_sp <= 1 || !ws) {
-        hipLaunchKernelGGL((prefill_gemm_kernel<EPI, NS>), dim3(tiles), dim3(256), lds_bytes(NS), s, A, B, bias, C, M, N, K,
+        hipLaunchKernelGGL((prefill_gemm_kernel<EPI, NS, NSPL>), dim3(tiles), dim3(256), lds_bytes(NS), s, A, B, bias, C, M, N, K,
                            ldc, (unsigned)tiles_n | (1u << 12) | ((unsigned)nsplit << 24), tiles, qa);
     } else {
-        hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL, NS>), dim3(tiles, n_sp), dim3(256), lds_bytes(NS), s, A, B, bias,
+        hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL, NS, NSPL>), dim3(tiles, n_sp), dim3(256), lds_bytes(NS), s, A, B, bias,
                            (void*)ws, M, N, K, ldc, (unsigned)tiles_n | ((unsigned)n_sp << 12) | ((unsigned)nsplit << 24), tiles, qa);
         if (EPI == PF_RESID && ln && ldc == N && N <= 2048) {
             hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, n_sp, bias,
@@ -399,6 +432,13 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
     ZG_HIP(hipGetLastError());
     if (EPI == PF_RESID && ln) return launch_ln_split(reinterpret_cast<const float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out, s);
     return ZG_OK;
+}
+
+template <int EPI, int NS>
+int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
+                           float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, int nsplit, hipStream_t s) {
+    if (nsplit == 2) return launch_prefill_gemm_np<EPI, NS, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
+    return launch_prefill_gemm_np<EPI, NS, kSplit>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
 }
 
 // 128 x 256 tiles (the staged weight tile is shared by the three planes, so widening N is the cheap direction:
