@@ -1558,11 +1558,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // waves, and 2.0-3.3 k in the epilogue that wave 0 runs alone for all 128 outputs of the tile (some 450 VALU
 // instructions at 4 cycles each) — with the planes coming from global memory nothing is left that 16 waves would
 // share.  Here every lane issues all its loads at entry (weights as full 128-byte lines through a wave-private
-// transposing LDS slot, A fragments of its own pairs, its epilogue operands, its share of x for the LayerNorm
-// statistics), the waves meet once, and each wave finishes ONE accumulator register of the tile: lane (n = lane & 15,
-// half = lane >> 4 < 2) of wave w owns output (m = 4 half + w, n).  K slices over blockIdx.y (KSL > 1) combine per
-// wave: wave w of every slice publishes its 32 outputs, takes a ticket on counter [tile][w], and the last arriver adds
-// the slices in fixed order — no workgroup barrier on that path either.
+// transposing LDS slot, A fragments of its own pairs, its epilogue operands, the LayerNorm statistics — tile sums the
+// producer of x wrote, or its share of x itself), the waves meet once, and each wave finishes ONE accumulator register
+// of the tile: lane (n = lane & 15, half = lane >> 4 < 2) of wave w owns output (m = 4 half + w, n).  K slices over
+// blockIdx.y (KSL > 1) combine per wave, without a workgroup barrier: by tagged data (slices 1.. store (value, tag)
+// words, slice 0 polls them and adds in slice order) or, without an epoch word, by a ticket on counter [tile][w] whose
+// last arriver adds the slices in fixed order.
 // KP = 64-k pairs per wave (K <= 256 KP per slice).
 // ================================================================================================
 // Arguments: everything an address of the up-front loads depends on sits in the first 16 dwords, which the hardware
@@ -1570,7 +1571,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // scalar load from the kernarg segment first, ~2 k ticks on a cold launch (the first version took W alone as a leading
 // argument and spent 3.4 k of its 7.4 k ticks before the last load was issued).  14 dwords are preloaded (16 user SGPRs less
 // the kernarg pointer): W, pl_in, xg, nk, flags, e0, e1, cp = 14.  nk = N | K << 16 (K = slice width), flags = M |
-// prologue << 4 | epilogue << 8; behind a folded LayerNorm xg = x (rows K apart, for the statistics), e0 = c2, e1 = c3;
+// prologue << 4 | epilogue << 8 | operand bits; behind a folded LayerNorm xg = the tile statistics [8][K / 16][2] (flags bit
+// 15) or x (rows K apart), e0 = c2, e1 = c3;
 // otherwise xg = gain of the planes written, e0 = bias, e1 = residual (rows N apart) — a few zero floats stand in for an
 // absent one (flags bits 12..14 say which are real; the loads are unconditional and read index 0 then: a load inside a
 // branch makes the compiler wait for it, and with it for every load issued before, at the join); cp = the step control
