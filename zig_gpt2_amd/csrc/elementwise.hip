@@ -158,10 +158,21 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         // speculative fetch of this sequence's partial maxima (valid memory whether or not needed)
         float bv = -3.0e38f;
         int bi = 0x7fffffff;
-        for (int p = lane; p < npart; p += 64) {
-            const float v = a.part_val[(size_t)b * a.part_stride + p];
-            const int i = a.part_idx[(size_t)b * a.part_stride + p];
-            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        // eight partials per lane per round, loads first and branch-free (clamped): a load-compare loop is one dependent memory
+        // round trip per 64 partials — seven of them for the 393 partials of 124M, most of this kernel's time
+        for (int base = 0; base < npart; base += 512) {
+            float pv[8];
+            int pi[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = min(base + lane + 64 * j, npart - 1);
+                pv[j] = a.part_val[(size_t)b * a.part_stride + p];
+                pi[j] = a.part_idx[(size_t)b * a.part_stride + p];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // (a clamped duplicate of the last partial changes nothing)
+                if (pv[j] > bv || (pv[j] == bv && pi[j] < bi)) { bv = pv[j]; bi = pi[j]; }
+            }
         }
         {   // the argument-block fields used behind the partial-maxima loads (zg_common.h ZG_PIN)
             ZG_PIN(a.forced); ZG_PIN(a.wte); ZG_PIN(a.wpe); ZG_PIN(a.weight_type); ZG_PIN(a.n_embed); ZG_PIN(a.cur_token); ZG_PIN(a.out_tokens);
@@ -181,11 +192,25 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         const int p_cur = a.prompt[(size_t)b * a.prompt_stride + min(s, a.prompt_stride - 1)];
         const int p_last = a.prompt[(size_t)b * a.prompt_stride + max(min(np, a.prompt_stride) - 1, 0)];
         const int forced = a.forced[b];
+        // argmax over the wave: DPP row rotations inside the 16-lane rows, then the four row winners through v_readlane
+        // (six rounds of ds_bpermute pairs were ~0.3 us of dependent LDS-crossbar hops)
+#define ZG_AM_STEP(N)                                                                                                   \
+    {                                                                                                                   \
+        const float ov = dpp_row_ror<N>(bv);                                                                            \
+        const int oi = __builtin_amdgcn_update_dpp(0, bi, 0x120 | N, 0xF, 0xF, true);                                   \
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }                                                     \
+    }
+        ZG_AM_STEP(8) ZG_AM_STEP(4) ZG_AM_STEP(2) ZG_AM_STEP(1)
+#undef ZG_AM_STEP
+        {   // every lane folds in the four row winners (its own among them): all lanes end with the wave's pick
+            const float rv = bv;
+            const int ri = bi;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            for (int r = 0; r < 64; r += 16) {
+                const float ov = lane_value(rv, r);
+                const int oi = __builtin_amdgcn_readlane(ri, r);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
         }
         const int g = bi;
         // the greedy pick of step s-1 exists iff that step ran lm_head (main.zig:337)
