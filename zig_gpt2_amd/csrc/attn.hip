@@ -280,17 +280,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     f32x4 o4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (base < t_hi) {
         // ---- all K and V loads up front: position t = base + 4*i + g, dims 4*lr .. 4*lr+3
+        // Branch-free: positions at or beyond t_hi re-read the last valid row (their probability is exactly 0 below: t >= t_hi
+        // >= T).  With `if (t < t_hi) load else 0` the compiler merged one loaded component with its zero in a fresh
+        // register right behind the second pair of loads — a vmcnt wait, i.e. a whole memory round trip, in the middle of
+        // the load sequence, with 14 of the 16 pairs not yet issued.
         f32x4 k4[16], v4[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int t = base + 4 * i + g;
-            if (t < t_hi) {
-                k4[i] = load_kv4<KV>(K + (size_t)t * stride_t + lr * 4);
-                v4[i] = load_kv4<KV>(V + (size_t)t * stride_t + lr * 4);
-            } else {
-                k4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                v4[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
+            const int t = min(base + 4 * i + g, t_hi - 1);
+            k4[i] = load_kv4<KV>(K + (size_t)t * stride_t + lr * 4);
+            v4[i] = load_kv4<KV>(V + (size_t)t * stride_t + lr * 4);
         }
         ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt);
         pf_count(a.progress);
@@ -414,17 +413,11 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
     float o[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (base < t_hi) {
         h8 k8[8], v8[8];
-        const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = base + 8 * i + g8;
-            if (t < t_hi) {
-                k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * stride_t + c * 8);
-                v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * stride_t + c * 8);
-            } else {
-                k8[i] = zero8;
-                v8[i] = zero8;
-            }
+        for (int i = 0; i < 8; ++i) {  // branch-free, as above
+            const int t = min(base + 8 * i + g8, t_hi - 1);
+            k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * stride_t + c * 8);
+            v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * stride_t + c * 8);
         }
         ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt);
         pf_count(a.progress);
