@@ -89,3 +89,26 @@ def test_fp16_cache_with_planes(zg, monkeypatch):
     b, lb = run_variant(monkeypatch, {"ZGPT2_NO_PLANES": "1"}, cfg, w, 4, prompts, cfg.context_size, kv_f16=True)
     assert np.array_equal(a, b)
     assert np.abs(la - lb).max() <= 2e-4 * np.abs(la).max()
+
+
+def test_timed_out_hand_over_fails_the_call(zg, monkeypatch):
+    """The pollers of the tagged hand-overs give up after a bounded number of polls, raise a fault word, and the call that
+    drains the stream fails instead of returning tokens computed from partial sums that never arrived.  With the bound
+    at zero every poll that does not find its writers' tags at once is a time-out (the first poll of a K slice practically
+    never does); the next handle, with the normal bound, is unaffected."""
+    from zig_gpt2_amd import _lib
+
+    cfg = synth.CONFIGS["medium-slice"]  # E = 1024: mlp c_proj in four K slices, hand-over in every layer of every step
+    w = synth.make_weights(cfg, seed=9, bf16=True)
+    prompts = [synth.rand_tokens(90 + b, 1, cfg.vocab_size) for b in range(8)]
+    monkeypatch.setenv("ZGPT2_TAG_SPIN_LIMIT", "0")
+    m = zgpt.GPT(cfg, batch=8)
+    m.load_weights(w)
+    with pytest.raises(_lib.ZgError, match="hand-over"):
+        for _ in range(4):  # (one generation is several hundred hand-overs; four to be sure one of them has to wait)
+            m.generate(prompts, cfg.context_size)
+    m.close()
+    monkeypatch.delenv("ZGPT2_TAG_SPIN_LIMIT")
+    ids, _ = run_variant(monkeypatch, {}, cfg, w, 8, prompts, 32)
+    ids2, _ = run_variant(monkeypatch, VARIANTS["tickets"], cfg, w, 8, prompts, 32)
+    assert np.array_equal(ids, ids2)

@@ -64,6 +64,8 @@ struct zg_gpt {
     int* attn_cnt;
     // tagged hand-overs (GemvArgs.sk_tag, AttnArgs.part_tag): step counter advanced by the embed kernel, (value, tag) words
     unsigned* epoch;
+    unsigned spin_limit;  // polls before a poller of a tagged hand-over gives up
+    unsigned* fault;  // set by a poller of a tagged hand-over whose bounded wait ran out; checked wherever a call drains the stream
     unsigned long long *sk_tag, *part_tag;
     bool tags_on;
     // LayerNorm statistics of x by 16-column tile, written by the producers of x (GemvArgs.st_out / st_in)
@@ -174,6 +176,7 @@ void carve(zg_gpt* g, char* base) {
     g->ap = (bf16_t*)P(E * 48);
     g->attn_cnt = (int*)P(8 * c.n_heads * 4);
     g->epoch = (unsigned*)P(256);
+    g->fault = (unsigned*)P(256);
     g->xst = (float*)P(((E + 15) / 16) * 8 * 2 * 4);
     g->sk_tag = (unsigned long long*)P(((E + 15) / 16) * 4 * 128 * 8);
     g->part_tag = (unsigned long long*)P(8 * c.n_heads * g->max_splits * kPartStride * 8);
@@ -400,6 +403,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                     a.epoch = g->epoch;
                     a.launch_id = launch_id(l, 0);
                     a.part_tag = g->part_tag;
+                    a.fault = g->fault;
+                    a.spin_limit = g->spin_limit;
                 }
             }
             if (rec) {  // the K and V rows of earlier positions, laid out for this grid
@@ -474,6 +479,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                     a.epoch = g->epoch;
                     a.launch_id = launch_id(l, 1);
                     a.sk_tag = g->sk_tag;
+                    a.fault = g->fault;
+                    a.spin_limit = g->spin_limit;
                 }
                 a.pl_in = g->hp;
                 if (l + 1 < g->cfg.n_layer) {  // the next Block's ln_1 + c_attn (ln_f + lm_head reads x itself)
@@ -563,6 +570,19 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
                                    g->pf_ws_floats, more ? &ln1 : nullptr, s, nullptr, np));
     }
     return ZG_OK;
+}
+
+// The tagged hand-overs of the lock-step batch poll with a bound; a poller that ran into it raised the fault word.  The
+// results of such a step are wrong, so the call that drains the stream fails (and clears the word for the next call).
+int check_fault(zg_gpt* g, hipStream_t s) {
+    if (!g->tags_on) return ZG_OK;
+    unsigned f = 0;
+    ZG_HIP(hipMemcpyAsync(&f, g->fault, sizeof(f), hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    if (f == 0) return ZG_OK;
+    (void)hipMemsetAsync(g->fault, 0, sizeof(unsigned), s);
+    set_error("a tagged hand-over of the decode step timed out (a workgroup waited 2^20 polls for its writers): results discarded");
+    return ZG_ERR_HIP;
 }
 
 int env_int(const char* name, int dflt) {
@@ -846,6 +866,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
                    gemv_planes_ok(a5, g->wt);
     }
     g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
+    g->spin_limit = (unsigned)env_int("ZGPT2_TAG_SPIN_LIMIT", 1 << 20);
     g->st_on = false;
     if (g->pl_on && !env_int("ZGPT2_NO_TILE_STATS", 0) && c.n_embed % 16 == 0 && c.n_embed / 16 <= 128) {
         // every producer and consumer of x must be the four-wave kernel
@@ -1030,7 +1051,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     }
     // h_ints / h_ctrl are reused by the next call: drain before returning.
     ZG_HIP(hipStreamSynchronize(s));
-    return ZG_OK;
+    return check_fault(g, s);
 }
 
 int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t n_tokens, int compute_logits,
@@ -1205,6 +1226,7 @@ int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t 
     hipStream_t s = ctx().stream;
     ZG_HIP(hipMemcpyAsync(g->h_ints, g->out_tokens, B * C * sizeof(int), hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
+    ZG_TRY(check_fault(g, s));
     for (size_t b = 0; b < B; ++b)
         for (size_t i = 0; i < n_steps; ++i) out_tokens[b * n_steps + i] = (size_t)g->h_ints[b * C + i];
     return ZG_OK;

@@ -139,7 +139,11 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, 
                     vl[s - 1] = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = ok && (unsigned)(vo[s - 1] >> 32) == tag && (unsigned)(vm[s - 1] >> 32) == tag && (unsigned)(vl[s - 1] >> 32) == tag;
                 }
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0 || spins > (1 << 20)) break;  // bounded: never hang the queue
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                if ((unsigned)spins >= a.spin_limit) {  // bounded: never hang the queue — and never pass silently
+                    if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
             float ms[MAXS], ls[MAXS], os[MAXS];
@@ -169,7 +173,11 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, 
                     vm = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     vl = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool ok = (unsigned)(vo >> 32) == tag && (unsigned)(vm >> 32) == tag && (unsigned)(vl >> 32) == tag;
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0 || spins > (1 << 20)) break;
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                    if ((unsigned)spins >= a.spin_limit) {
+                        if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const float m_s = __uint_as_float((unsigned)vm);
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             k4[i] = load_kv4<KV>(K + (size_t)t * stride_t + lr * 4);
             v4[i] = load_kv4<KV>(V + (size_t)t * stride_t + lr * 4);
         }
-        ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt);
+        ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt); ZG_PIN(a.fault); ZG_PIN(a.spin_limit);
         pf_count(a.progress);
         // ---- partial dots, then reduce-scatter: lane (g, j) ends with the score of t = base + 4*j + g
         float s[16];
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
             k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * stride_t + c * 8);
             v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * stride_t + c * 8);
         }
-        ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt);
+        ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt); ZG_PIN(a.fault); ZG_PIN(a.spin_limit);
         pf_count(a.progress);
         float s[8];
 #pragma unroll

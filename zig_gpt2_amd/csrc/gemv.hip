@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
             ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_f16);
         }
         if constexpr (KSL > 1) {
-            ZG_PIN(a.sk_tag); ZG_PIN(a.launch_id); ZG_PIN(a.sk_ws); ZG_PIN(a.sk_cnt);
+            ZG_PIN(a.sk_tag); ZG_PIN(a.launch_id); ZG_PIN(a.sk_ws); ZG_PIN(a.sk_cnt); ZG_PIN(a.fault); ZG_PIN(a.spin_limit);
         }
     }
     const int T = (int)cpw;
@@ -1775,7 +1775,11 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
                     v[ks] = __hip_atomic_load(slot + ks * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = ok && (unsigned)(v[ks] >> 32) == tag;
                 }
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0 || spins > (1 << 20)) break;  // bounded: never hang the queue
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                if ((unsigned)spins >= a.spin_limit) {  // bounded: never hang the queue — and never pass silently
+                    if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll

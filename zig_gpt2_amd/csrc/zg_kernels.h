@@ -82,6 +82,8 @@ struct GemvArgs {
     const unsigned* epoch;
     unsigned launch_id;
     unsigned long long* sk_tag;
+    unsigned* fault;  // set to 1 by a poller whose bounded wait ran out (the host fails the call loudly: api_gpt.hip check_fault)
+    unsigned spin_limit;  // polls before a poller gives up (2^20; ZGPT2_TAG_SPIN_LIMIT for the test of the failure path)
     // LayerNorm statistics by tile: a producer of x (four-wave plane-fed kernel, embed kernel) also writes, per 16-column tile
     // and batch row, the sum and the sum of squares of its 16 outputs, st_out [8][N / 16][2]; the LayerNorm-fed consumer
     // adds the tiles (st_in) instead of reading x again — a third of its vector-memory traffic
@@ -132,6 +134,8 @@ struct AttnArgs {
     const unsigned* epoch;
     unsigned launch_id;
     unsigned long long* part_tag;
+    unsigned* fault;  // see GemvArgs.fault
+    unsigned spin_limit;
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t s);
 // Standalone merge (op tier): out[b][h*hd+d] = sum_s w_s o_s / sum_s w_s l_s
