@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "../../include/zgpt2.h"
@@ -32,8 +33,10 @@ int main(int argc, char** argv) {
     bool check = true, gelu = true, out_bf16 = true, stamps = false;
     int fill = 0;  // 0 random (A uniform(-1,1), B normal(0, 0.02)), 1 all zero, 2 constant 1.0 / 0.02, 3 random sign only
     const char* kern = nullptr;
+    const char* refk = nullptr;  // -ref <kernel>: the output must be bitwise that of this other kernel generation
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-k")) kern = argv[++i];
+        else if (!strcmp(argv[i], "-ref")) refk = argv[++i];
         else if (!strcmp(argv[i], "-b")) batches = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-i")) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-nocheck")) check = false;
@@ -90,6 +93,21 @@ int main(int argc, char** argv) {
         printf("check %dx%dx%d %s: %d rows sampled, bad %d, max abs err %.3g, repeatable %s\n", M, N, K, getenv("ZGPT2_GEMM_KERNEL") ? getenv("ZGPT2_GEMM_KERNEL") : "default",
                nrows, bad, worst, same ? "yes" : "NO");
         if (bad || !same) return 1;
+        if (refk) {
+            const char* mine = getenv("ZGPT2_GEMM_KERNEL");
+            std::string keep = mine ? mine : "";
+            setenv("ZGPT2_GEMM_KERNEL", refk, 1);
+            CK(hipMemset(dC, 0xFF, (size_t)M * N * esz));
+            CK(hipDeviceSynchronize());
+            run();
+            fetch(h1);
+            size_t diff = 0, first = 0;
+            for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) { if (!diff) first = i; ++diff; }
+            printf("bitwise against %s: %zu differing bytes of %zu%s\n", refk, diff, h0.size(), diff ? "  <-- MISMATCH" : "");
+            if (diff) printf("  first at element %zu (row %zu, col %zu): %g vs %g\n", first / esz, first / esz / N, first / esz % N, val(h0, first / esz), val(h1, first / esz));
+            if (mine) setenv("ZGPT2_GEMM_KERNEL", keep.c_str(), 1); else unsetenv("ZGPT2_GEMM_KERNEL");
+            if (diff) return 1;
+        }
     }
     for (int i = 0; i < 300; ++i) run();  // clocks settle
     CK(hipStreamSynchronize(st));
@@ -108,7 +126,7 @@ int main(int argc, char** argv) {
            getenv("ZGPT2_GEMM_KERNEL") ? getenv("ZGPT2_GEMM_KERNEL") : "default", getenv("ZGPT2_GEMM_DBG") ? getenv("ZGPT2_GEMM_DBG") : "0", best,
            flops / best / 1e6, flops / best / 1e6 / 25.0, mean, flops / mean / 1e6, flops / mean / 1e6 / 25.0);
     if (stamps && zg_debug_gemm_stamps) {
-        std::vector<unsigned long long> w(1 + 2 * 256 + 16);
+        std::vector<unsigned long long> w(1 + 4 * 256 + 16);
         ZK(zg_debug_gemm_stamps(w.data(), w.size()));
         const int g = (int)std::min<unsigned long long>(w[0], 256);
         // per XCD (workgroup b runs on XCD b % 8; the cycle counter is per XCD): span from the first start to the last end
@@ -119,8 +137,17 @@ int main(int argc, char** argv) {
             span_max = std::max(span_max, (double)(e1 - s0));
         }
         for (int b = 0; b < g; ++b) { const double d = (double)(w[2 + 2 * b] - w[1 + 2 * b]); dmin = std::min(dmin, d); dmax = std::max(dmax, d); dsum += d; }
-        printf("stamps: %d workgroups, cycles min %.0f avg %.0f max %.0f; widest XCD span %.0f cycles = %.2f GHz against the mean launch time\n", g, dmin,
-               dsum / g, dmax, span_max, span_max / mean / 1e3);
+        // wall time inside the launch (100 MHz s_memrealtime: one counter for the whole chip): first start .. last end
+        unsigned long long ws = ~0ull, we = 0, wls = 0;
+        double wsum = 0;
+        for (int b = 0; b < g; ++b) { ws = std::min(ws, w[513 + 2 * b]); we = std::max(we, w[514 + 2 * b]); wls = std::max(wls, w[513 + 2 * b]); wsum += (double)(w[514 + 2 * b] - w[513 + 2 * b]); }
+        const double wall_us = (double)(we - ws) / 100.0, wg_us = wsum / g / 100.0;
+        printf("stamps: %d workgroups, cycles min %.0f avg %.0f max %.0f; widest XCD span %.0f cycles\n", g, dmin, dsum / g, dmax, span_max);
+        printf("stamps: wall inside the launch %.2f us (first start .. last end; last start %.2f us after the first), mean workgroup %.2f us -> shader clock %.2f GHz; "
+               "launch-to-launch %.2f us -> %.2f us outside the workgroups\n", wall_us, (double)(wls - ws) / 100.0, wg_us, dsum / g / wg_us / 1e3, mean, mean - wall_us);
+        printf("stamps: workgroup 0 phases (cycles since start):");
+        for (int i = 1; i < 16 && w[1025 + i]; ++i) printf(" %llu", w[1025 + i] - w[1025]);
+        printf("\n");
     }
     return 0;
 }

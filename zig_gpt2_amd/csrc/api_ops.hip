@@ -375,7 +375,7 @@ int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_n
 }
 
 unsigned long long zg_debug_gemm_launches(void) { return gemm_mfma_launch_count(); }
-int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words) { return gemm_s4_stamps(out, n_words); }
+int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words) { return gemm_debug_stamps(out, n_words); }
 int zg_debug_last_kernel(char* out, size_t n) {
     if (!out || n == 0) return ZG_ERR_ARG;
     snprintf(out, n, "%s", zg::g_kernel);

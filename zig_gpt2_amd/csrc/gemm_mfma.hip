@@ -524,6 +524,10 @@ int launch_p8_bn(const bf16_t* A, const bf16_t* B, const float* bias, void* C, i
 
 static unsigned long long g_gemm_launches = 0;
 unsigned long long gemm_mfma_launch_count() { return g_gemm_launches; }
+static int g_last_gemm_kernel = 0;  // 0 s4 / p8, 1 ov
+int gemm_debug_stamps(unsigned long long* out, size_t n_words) {
+    return g_last_gemm_kernel == 1 ? gemm_ov_stamps(out, n_words) : gemm_s4_stamps(out, n_words);
+}
 
 int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl,
                        int ldc, bool gelu, bool out_bf16, hipStream_t s) {
@@ -564,7 +568,14 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     // choice (its 256-wide instantiation does not fit the register file without spills yet), the eight-wave one below
     // for 256-wide tiles.  ZGPT2_GEMM_KERNEL=p8 / s4 forces one (s4 then always with 192-wide tiles).
     const char* kk = getenv("ZGPT2_GEMM_KERNEL");
-    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8");
+    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8"), force_ov = kk && !strcmp(kk, "ov");
+    // bf16 results: the third generation (gemm_ov.hip) hides a tile's epilogue under the next tile's main loop
+    // — measured SLOWER than gemm_s4 at two tiles per workgroup: an experiment, only on request
+    if (out_bf16 && gemm_ov_args_ok(M, pl, ldc) && force_ov) {
+        g_last_gemm_kernel = 1;
+        return launch_gemm_ov(A, B, bias, C, M, N, pl, ldc, gelu, s);
+    }
+    g_last_gemm_kernel = 0;
     if (force_s4 || ragged || (!force_p8 && bn == 192)) return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, 192, s);
     return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
                      : launch_p8_bn<256>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);

@@ -25,7 +25,10 @@
 
 namespace zg {
 
-__device__ unsigned long long g_s4_stamps[1 + 2 * 256 + 16];  // diagnostic (dbg bit 256): shader-clock {start, end} of every workgroup's wave 0
+// diagnostic (dbg bit 256): [0] grid; [1 + 2 b ..] shader-clock {start, end} of workgroup b's wave 0; [513 + 2 b ..] the same two moments on the
+// constant 100 MHz clock (s_memrealtime: wall time inside the launch, whatever the shader clock does); [1025 ..] workgroup 0's phase
+// stamps (shader clock): start, prologue done, then {main loop done, epilogue done} per tile
+__device__ unsigned long long g_s4_stamps[1 + 4 * 256 + 16];
 
 namespace {
 
@@ -214,8 +217,19 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     int idx = t_begin + loc;
     if (idx >= t_end) return;
     const bool stamp = (dbg & 256) && wave == 0 && bid < 256;
-    unsigned long long t_start = 0;
-    if (stamp) t_start = __builtin_readcyclecounter();
+    unsigned long long t_start = 0, w_start = 0;
+    int n_phase = 0;
+    if (stamp) {
+        t_start = __builtin_readcyclecounter();
+        w_start = __builtin_amdgcn_s_memrealtime();
+    }
+    auto phase_stamp = [&]() {
+        if (stamp && bid == 0 && n_phase < 16) {
+            if (lane == 0) g_s4_stamps[1025 + n_phase] = __builtin_readcyclecounter();
+            ++n_phase;
+        }
+    };
+    phase_stamp();
 
     // ---- DMA sources.  A piece = 8 unit rows x 128 B, written lane-linearly (lane -> row lane / 8, 16-B position
     // lane % 8); position p of LDS row R holds source chunk p ^ ((R >> 1) & 7) (the swizzle the fragment reads undo).
@@ -288,6 +302,11 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // diagnostic ablations, compile time (ZGPT2_S4_ABL; timing only, wrong results): 1 no DMA, 2 no barriers, 4 no fragment reads,
     // 8 no waits on the fragment reads
     constexpr bool abl_dma = ABL & 1, abl_bar = ABL & 2, abl_rd = ABL & 4, abl_lgkm = ABL & 8;
+    // Cache policy of the bf16 output stores: sc1 = write-through.  With plain stores the launch ends with the L2s writing
+    // their dirty lines back — 4.2 us between the last workgroup's end and the next launch's first workgroup against 2.0 us
+    // with write-through stores, at +0.6 us inside the launch (41.5 -> 40.2 us at M = 8192, profiles/round4_gemm_a.txt).
+    // A/B: ABL bits 16 / 32 -> nt (aux 2), plain (0), sc0 sc1 (17).
+    constexpr int ST_AUX = ((ABL >> 4) & 3) == 1 ? 2 : ((ABL >> 4) & 3) == 2 ? 0 : ((ABL >> 4) & 3) == 3 ? 17 : 16;
     auto dma_a = [&](int X, int h, int i, const Ahead& s) {
         if constexpr (abl_dma) return;
         const unsigned rowd = (unsigned)((i >> 1) * 128 + h * 64 + (i & 1) * 32);
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     const unsigned off = g_off[k] == 0xFFFFFFFFu ? g_off[k] : g_off[k] + (unsigned)(i * 32) * (unsigned)(ldc * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(o[k], rc, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o[k], rc, off, 0, ST_AUX);
                 }
             }
         });
@@ -655,6 +674,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         bar();
         init_acc_from_bias(0);  // (wave 0's bias pieces were the first of the stream: landed with the wait above)
         read_kstep_head(Ic<0>{});
+        phase_stamp();
     }
 
     // two K-steps per trip so that the slot is a compile-time constant; a tile may end after either
@@ -662,7 +682,9 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         kstep(Ic<0>{});
         if (advance()) {
             settle();
+            phase_stamp();
             epilogue();
+            phase_stamp();
             if (idx + gx >= t_end) break;
             next_tile();
             read_kstep_head(Ic<1>{});
@@ -671,7 +693,9 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         kstep(Ic<1>{});
         if (advance()) {
             settle();
+            phase_stamp();
             epilogue();
+            phase_stamp();
             if (idx + gx >= t_end) break;
             next_tile();
             read_kstep_head(Ic<0>{});
@@ -684,6 +708,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         g_s4_stamps[0] = gridDim.x;
         g_s4_stamps[1 + 2 * bid] = t_start;
         g_s4_stamps[2 + 2 * bid] = __builtin_readcyclecounter();
+        g_s4_stamps[513 + 2 * bid] = w_start;
+        g_s4_stamps[514 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -732,6 +758,9 @@ int launch_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int 
             case 8: return launch_s4_abl<NT, GELU, OUT_BF16, 8>(A, B, bias, C, M, N, pl, ldc, s);
             case 9: return launch_s4_abl<NT, GELU, OUT_BF16, 9>(A, B, bias, C, M, N, pl, ldc, s);
             case 11: return launch_s4_abl<NT, GELU, OUT_BF16, 11>(A, B, bias, C, M, N, pl, ldc, s);
+            case 16: return launch_s4_abl<NT, GELU, OUT_BF16, 16>(A, B, bias, C, M, N, pl, ldc, s);
+            case 32: return launch_s4_abl<NT, GELU, OUT_BF16, 32>(A, B, bias, C, M, N, pl, ldc, s);
+            case 48: return launch_s4_abl<NT, GELU, OUT_BF16, 48>(A, B, bias, C, M, N, pl, ldc, s);
             default: break;
         }
     }
@@ -750,7 +779,7 @@ int launch_s4_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, i
 }  // namespace
 
 int gemm_s4_stamps(unsigned long long* out, size_t n_words) {
-    if (n_words > 1 + 2 * 256 + 16) n_words = 1 + 2 * 256 + 16;
+    if (n_words > 1 + 4 * 256 + 16) n_words = 1 + 4 * 256 + 16;
     ZG_HIP(hipDeviceSynchronize());
     ZG_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s4_stamps), n_words * sizeof(unsigned long long)));
     return ZG_OK;

@@ -176,6 +176,12 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
 int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
                    bool gelu, bool out_bf16, int bn, hipStream_t s);  // gemm_s4.hip
 int gemm_s4_stamps(unsigned long long* out, size_t n_words);  // diagnostic (ZGPT2_GEMM_DBG bit 256)
+// bf16 result, 192-wide tiles, the epilogue of a tile under the next tile's main loop (gemm_ov.hip)
+bool gemm_ov_args_ok(int M, const GemmPlanes& pl, int ldc);
+int launch_gemm_ov(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, bool gelu,
+                   hipStream_t s);
+int gemm_ov_stamps(unsigned long long* out, size_t n_words);
+int gemm_debug_stamps(unsigned long long* out, size_t n_words);  // of the kernel generation launched last
 unsigned long long gemm_mfma_launch_count();  // launches of the MFMA GEMM so far (tests assert the path taken)
 
 // ------------------------------------------------------------------------------------ prefill (prefill.hip)
