@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-prefetch", action="store_true", help="no side-stream L2 prefetcher beside the decode chain (A/B)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the secondary block (8 prompts, XL, nano-char)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--dry-run", action="store_true",
@@ -180,6 +181,106 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
     }
 
 
+def kernel_table(model, lib, cfg, ppg, wsz, kv_elem):
+    """Every kernel class of the decode step timed live: HIP events on the launch stream around a hipGraph chain of 64
+    launches of that one kernel at a mid-context control block (launch boundary included), priced per token by its launch
+    count.  Returns (table, dominant class, lm_head row)."""
+    from zig_gpt2_amd import _lib
+
+    E, L, V = cfg.n_embed, cfg.n_layer, cfg.vocab_size
+    t_mid = max(cfg.context_size // 2, 1)
+    classes = [  # (time_kernel id, name, launches per token, algorithmic bytes per launch)
+        (1, "ln_1 + c_attn + KV append", L, 3 * E * E * wsz),
+        (2, "attention (split-KV decode)", L, 2 * t_mid * E * kv_elem * ppg),
+        (3, "head merge + attn c_proj + residual", L, E * E * wsz),
+        (4, "ln_2 + c_fc + GELU", L, 4 * E * E * wsz),
+        (5, "mlp c_proj + residual", L, 4 * E * E * wsz),
+        (6, "ln_f + lm_head + argmax", 1, V * E * wsz),
+    ]
+    table = []
+    for which, name, n_launch, nbytes in classes:
+        os.environ["ZGPT2_TIME_CYCLE"] = "0"
+        us, _ = model.time_kernel(which, 256)
+        os.environ["ZGPT2_TIME_CYCLE"] = "1"  # walk the layers: weights / KV from the memory side, as in the real step
+        us_cold, _ = model.time_kernel(which, 256)
+        os.environ["ZGPT2_TIME_CYCLE"] = "0"
+        sym = C.create_string_buffer(160)
+        _lib.check(lib.zg_debug_last_kernel(sym, 160))
+        table.append({"class": name, "kernel_symbol": sym.value.decode(), "launches_per_token": n_launch, "avg_launch_us": round(us, 3),
+                      "avg_launch_us_layers_walked": round(us_cold, 3),
+                      "algorithmic_bytes_per_launch": int(nbytes), "GBps": round(nbytes / us / 1e3, 1),
+                      "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_token": round(us * n_launch, 2)})
+    tot_us = sum(r["us_per_token"] for r in table)
+    for r in table:
+        r["share_of_token_time"] = round(r["us_per_token"] / tot_us, 4)
+    return table, max(table, key=lambda r: r["us_per_token"]), table[-1]
+
+
+def device_weights(cfg, seed):
+    """bf16-representable N(mean, 0.02^2) weights generated ON the GPU (torch): the secondary configurations are timed, not
+    compared with the oracle, and numpy needs half a minute for GPT-2 XL's 1.5 G parameters."""
+    import torch
+
+    from zig_gpt2_amd import synth
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    w = {}
+    for name, shape, mean, _ in synth.tensor_specs(cfg):
+        t = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32) * 0.02 + mean
+        w[name] = t.to(torch.bfloat16).to(torch.float32).contiguous()
+    return w
+
+
+def other_config(lib, stream, model_name, ppg, gens, seed):
+    """One of BASELINE.json's other single-GPU workloads, driver-timed in the same run: tokens/s of `gens` full greedy
+    generations (after one warm-up generation), device time per forward, whole-step roofline fraction, dominant kernel class."""
+    import torch
+
+    from zig_gpt2_amd import gpt, synth
+
+    cfg = synth.CONFIGS[model_name]
+    ctx = cfg.context_size
+    model = gpt.GPT(cfg, batch=ppg)
+    try:
+        w = device_weights(cfg, seed)
+        model.load_weights(w)
+        del w
+        prompts = [synth.rand_tokens(2000 + seed * 131 + b, 1, cfg.vocab_size) for b in range(ppg)]
+        model.generate_enqueue(prompts, ctx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(gens):
+            model.generate_enqueue(prompts, ctx)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        dev_s = e0.elapsed_time(e1) / 1e3
+        ids = model.generate_fetch(ctx)
+        pf = model.prefetch_stats()
+        wbytes, _ = model.step_bytes(1)
+        kv_total = sum(4 * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
+        step_bytes_total = wbytes * ctx + kv_total
+        table, dom, lm = kernel_table(model, lib, cfg, ppg, 2, 4)
+        return {
+            "workload": f"GPT-2 {model_name} greedy decode, {ppg} prompt(s) on one GPU, 1-token prompts, {ctx} decode steps per prompt",
+            "value": round(ppg * (ctx - 1) * gens / wall, 1), "unit": "tokens/s", "generations": gens, "ms_per_generation": round(1e3 * wall / gens, 3),
+            "us_per_forward_device": round(1e6 * dev_s / (gens * ctx), 2),
+            "kv_cache": "f32", "l2_prefetcher": ("stalled" if pf["stalled"] else "on") if pf["on"] else "off",
+            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_generation": int(step_bytes_total),
+                              "achieved": round(step_bytes_total * gens / dev_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(step_bytes_total * gens / dev_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "dominant_class": {k: dom[k] for k in ("class", "kernel_symbol", "avg_launch_us", "avg_launch_us_layers_walked", "algorithmic_bytes_per_launch",
+                                                   "GBps", "frac_of_8TBps", "share_of_token_time")},
+            "lm_head": {k: lm[k] for k in ("kernel_symbol", "avg_launch_us", "GBps", "frac_of_8TBps")},
+            "data": "synthetic (torch.randn on the GPU, bf16-representable)", "first_tokens": [int(t) for t in ids[0, :4]],
+        }
+    finally:
+        model.close()
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -286,37 +387,7 @@ def main():
     wbytes, _ = model.step_bytes(1)
     wsz = 4 if a.weights_f32 else 2
     kv_elem = 2 if a.kv_f16 else 4
-    E, L, V = cfg.n_embed, cfg.n_layer, cfg.vocab_size
-    t_mid = max(cfg.context_size // 2, 1)
-    classes = [  # (time_kernel id, name, launches per token, algorithmic bytes per launch)
-        (1, "ln_1 + c_attn + KV append", L, 3 * E * E * wsz),
-        (2, "attention (split-KV decode)", L, 2 * t_mid * E * kv_elem * ppg),
-        (3, "head merge + attn c_proj + residual", L, E * E * wsz),
-        (4, "ln_2 + c_fc + GELU", L, 4 * E * E * wsz),
-        (5, "mlp c_proj + residual", L, 4 * E * E * wsz),
-        (6, "ln_f + lm_head + argmax", 1, V * E * wsz),
-    ]
-    table = []
-    for which, name, n_launch, nbytes in classes:
-        os.environ["ZGPT2_TIME_CYCLE"] = "0"
-        us, _ = model.time_kernel(which, 256)
-        os.environ["ZGPT2_TIME_CYCLE"] = "1"  # walk the layers: weights / KV from the memory side, as in the real step
-        us_cold, _ = model.time_kernel(which, 256)
-        os.environ["ZGPT2_TIME_CYCLE"] = "0"
-        sym = C.create_string_buffer(160)
-        _lib.check(lib.zg_debug_last_kernel(sym, 160))
-        table.append({"class": name, "_symbol": sym.value.decode(), "launches_per_token": n_launch, "avg_launch_us": round(us, 3),
-                      "avg_launch_us_layers_walked": round(us_cold, 3),
-                      "algorithmic_bytes_per_launch": int(nbytes), "GBps": round(nbytes / us / 1e3, 1),
-                      "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_token": round(us * n_launch, 2)})
-    tot_us = sum(r["us_per_token"] for r in table)
-    for r in table:
-        r["share_of_token_time"] = round(r["us_per_token"] / tot_us, 4)
-    # the kernel instantiation behind every class, as noted by the library's launchers while the chain above was recorded
-    for r in table:
-        r["kernel_symbol"] = r.pop("_symbol")
-    dom = max(table, key=lambda r: r["us_per_token"])
-    lm = table[-1]
+    table, dom, lm = kernel_table(model, lib, cfg, ppg, wsz, kv_elem)
     n_prof = min(64, ctx)
     prof_lo = model.profile_step(1, n_prof)
     prof_hi = model.profile_step(ctx - n_prof + 1, n_prof)
@@ -339,7 +410,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_gemm
 
-            gemm = bench_gemm.measure(lib, 8192)
+            gemm = bench_gemm.measure(lib, 8192)  # BASELINE's point; the other heights beside it (fewer launches each)
+            gemm["other_M"] = [{k: v for k, v in bench_gemm.measure(lib, m, iters=20, batches=3, warm=100).items()
+                                if k in ("M", "us", "us_min", "tflops", "mfma_frac_of_2.5PF")} for m in (1024, 16384)]
             _lib.check(lib.zg_set_stream(stream.cuda_stream))
         except Exception as e:  # the headline metric must not die with the secondary one
             gemm = {"error": str(e)}
@@ -377,6 +450,19 @@ def main():
                                         "linear_tflops_useful": round(lin_flops / p2_ms / 1e9, 1)}
         except Exception as e:
             prefill = {"error": str(e)}
+    # BASELINE.json configs[2..4] on this GPU, one handle after another (the headline handle stays: its numbers are above)
+    others = None
+    if a.model == "124M" and world == 1 and ppg == 1 and not a.weights_f32 and not a.kv_f16 and not a.no_other_configs:
+        others = []
+        for mname, mp, gens in (("124M", 8, 2), ("xl", 1, 1), ("nano-char", 1, 3)):
+            try:
+                t_o = time.perf_counter()
+                o = other_config(lib, stream, mname, mp, gens, a.seed + 7)
+                o["seconds_spent"] = round(time.perf_counter() - t_o, 1)
+                others.append(o)
+            except Exception as e:
+                others.append({"workload": f"{mname} x {mp}", "error": str(e)})
+        _lib.check(lib.zg_set_stream(stream.cuda_stream))
     # whole-step view: algorithmic bytes of all ctx steps / device time
     kv_total = sum(kv_elem * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
     step_bytes_total = wbytes * ctx + kv_total
@@ -430,6 +516,7 @@ def main():
         },
         "mfma_gemm_768x3072": gemm,
         "prefill": prefill,
+        "other_configs": others,
         "device_time_s": round(dev_s, 4),
         "setup_s": round(setup_s, 2),
         "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),

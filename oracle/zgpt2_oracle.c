@@ -104,6 +104,8 @@ static cblas_sgemm_fn g_cblas = NULL;
 static void* g_cblas_handle = NULL;
 static int g_accum_double = 0;
 
+int orc_num_threads(void);
+
 /* Plug a real CBLAS in (timing only).  Returns 0 on success. */
 int orc_use_cblas(const char* lib_path, const char* symbol) {
     if (!lib_path) {
@@ -119,6 +121,17 @@ int orc_use_cblas(const char* lib_path, const char* symbol) {
     }
     g_cblas_handle = h;
     g_cblas = (cblas_sgemm_fn)f;
+    /* OpenBLAS sizes its thread pool from the CPUs it SEES (256 on a GPU box whose cgroup grants 16): left alone it
+     * oversubscribes the quota and runs an order of magnitude slow.  Hold it to the threads the port itself uses
+     * (OPENBLAS_NUM_THREADS = all usable cores). */
+    const char* setters[] = {"scipy_openblas_set_num_threads", "openblas_set_num_threads", "goto_set_num_threads"};
+    for (unsigned i = 0; i < sizeof(setters) / sizeof(setters[0]); ++i) {
+        void (*set_threads)(int) = (void (*)(int))dlsym(h, setters[i]);
+        if (set_threads) {
+            set_threads(orc_num_threads());
+            break;
+        }
+    }
     return 0;
 }
 

@@ -115,3 +115,56 @@ def test_gemm_768x3072_full_size_properties(zg):
     assert np.array_equal(y2, 2.0 * y0)
     rows = np.arange(0, m, 257)
     assert_ref_close(oracle.linear_forward(k, n, b, bias, a[rows]), y[rows], "gemm 8192 row sample", scale_floor=4e-6)
+
+
+def test_gemm_768x3072_timed_instantiation(zg):
+    """The instantiation bench.py times — bias + GELU + bf16 result at M = 8192 (gemm_s4_kernel<3, true, true, 0>, 512 tiles,
+    write-through stores): a row sample against the oracle within bf16 rounding, and the whole result equal to the fp32-output
+    run of the same kernel family rounded to the nearest bf16."""
+    m, n, k = 8192, 3072, 768
+    a = synth.fill_uniform(21, m * k, -1.0, 1.0, bf16=True).reshape(m, k)
+    b = synth.fill_normal(22, n * k, 0.0, 0.02, bf16=True).reshape(n, k)
+    bias = synth.fill_normal(23, n, 0.0, 0.02)
+    got = run_gemm(zg, a, b, bias, True, out_bf16=True)
+    f32 = run_gemm(zg, a, b, bias, True, out_bf16=False)
+    assert np.array_equal(got, synth.round_bf16(f32))
+    rows = np.arange(3, m, 251)
+    exp = oracle.gelu(oracle.linear_forward(k, n, b, bias, a[rows]))
+    # bf16 keeps 8 significant bits: half an ulp is 2^-9 of the value; the fp32 pre-activation itself is held to the
+    # reference tolerance by the fp32-output tests above
+    assert np.all(np.abs(got[rows] - exp) <= 2.0 ** -8 * np.abs(exp) + 1e-6), np.abs(got[rows] - exp).max()
+    assert_ref_close(exp, f32[rows], "gemm 8192 gelu row sample (fp32 out)", scale_floor=4e-6)
+
+
+def test_gemm_k_beyond_the_packed_arguments_runs_on_the_eight_wave_kernel(zg):
+    """K = 16384 (256 K-steps) is past gemm_s4_kernel's packed arguments: the dispatcher must fall through to gemm_p8_kernel
+    instead of failing; a ragged fp32 width, which only the four-wave kernel stores, is refused with ZG_ERR_UNSUPPORTED."""
+    import torch
+
+    m, n, k = 128, 256, 16384
+    a = synth.fill_normal(31, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
+    b = synth.fill_normal(32, n * k, 0.0, 0.01, bf16=True).reshape(n, k)
+    bias = synth.fill_normal(33, n, 0.0, 0.5)
+    got = run_gemm(zg, a, b, bias, False, out_bf16=False)
+    assert_ref_close(oracle.linear_forward(k, n, b, bias, a), got, "gemm K=16384", scale_floor=4e-6)
+    t = torch.zeros(128 * 16384, dtype=torch.int16, device="cuda")
+    c = torch.zeros(128 * 128, dtype=torch.float32, device="cuda")
+    assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 126, 16384, 0, 0) == -5
+
+
+@pytest.mark.parametrize("m,n,k,wgs", [(256, 192, 128, 0), (1100, 776, 320, 3), (2048, 1536, 768, 5)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_overlapped_epilogue_experiment_equals_the_four_wave_kernel(zg, m, n, k, wgs, gelu, monkeypatch):
+    """gemm_ov_kernel (ZGPT2_GEMM_KERNEL=ov; the epilogue of a tile under the next tile's main loop, DESIGN 8.1: measured
+    slower than gemm_s4 at two tiles per workgroup and not dispatched by default) computes the same fp32 values in the same
+    order: its bf16 output must be bitwise that of gemm_s4, also with several tiles per workgroup."""
+    if wgs:
+        monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
+    a = synth.fill_normal(41, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
+    b = synth.fill_normal(42, n * k, 0.0, 0.05, bf16=True).reshape(n, k)
+    bias = synth.fill_normal(43, n, 0.0, 0.5)
+    monkeypatch.setenv("ZGPT2_GEMM_KERNEL", "s4")
+    ref = run_gemm(zg, a, b, bias, gelu, out_bf16=True)
+    monkeypatch.setenv("ZGPT2_GEMM_KERNEL", "ov")
+    got = run_gemm(zg, a, b, bias, gelu, out_bf16=True)
+    assert np.array_equal(ref, got)

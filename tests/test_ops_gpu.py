@@ -130,6 +130,26 @@ def test_linear_large_batch_runs_on_the_matrix_cores(zg, m, k, n):
     assert_ref_close(y[:8], y8, "GEMV path vs MFMA path", scale_floor=2e-6)
 
 
+def test_linear_wider_than_the_four_wave_gemm_arguments(zg):
+    """in_features = 16384 at batch 16: rows of three planes (49152 elements) and 256 K-steps per plane are beyond what
+    gemm_s4_kernel's packed arguments express — the Linear must fall through to the eight-wave GEMM instead of failing
+    (the reference Linear has no size limit, src/ops.zig:21-46).  A ragged width, which only the four-wave kernel stores,
+    goes to the GEMV kernels, whose own bound (in_features <= 8192) then answers with ZG_ERR_UNSUPPORTED — loudly."""
+    m, k, n = 16, 16384, 128
+    w = synth.fill_normal(100 + n, n * k, 0, 0.02).reshape(n, k)
+    b = synth.fill_normal(200 + n, n, 0, 0.05)
+    x = synth.fill_normal(300 + m, m * k, 0, 1.0).reshape(m, k)
+    y = z(m, n)
+    before = zg.zg_debug_gemm_launches()
+    ops.Linear(k, n, w, b).forward(x, y)
+    assert zg.zg_debug_gemm_launches() == before + 1
+    assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n}", scale_floor=2e-6)
+    from zig_gpt2_amd._lib import ZgError
+    with pytest.raises(ZgError) as e:
+        ops.Linear(k, 130, np.ascontiguousarray(np.resize(w, (130, k))), None).forward(x, z(m, 130))
+    assert e.value.code == -5
+
+
 def test_registered_mirror_is_never_used_for_activations(zg):
     """src/tests.zig frees its weights (`defer allocator.free`) and allocates same-sized buffers next: a host
     address that once held a registered weight may come back as an `inputs` slice.  Activations must never be

@@ -10,7 +10,7 @@ from zig_gpt2_amd import _lib, synth
 PEAK_TF = 2500.0
 
 
-def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
+def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50, batches=5, warm=400):
     a = torch.from_numpy(synth.to_bf16_bits(synth.fill_uniform(1, m * k, -1, 1)).view(np.int16)).cuda()
     b = torch.from_numpy(synth.to_bf16_bits(synth.fill_normal(2, n * k, 0, 0.02)).view(np.int16)).cuda()
     bias = torch.from_numpy(synth.fill_normal(3, n, 0, 0.02)).cuda()
@@ -18,11 +18,11 @@ def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
     stream = torch.cuda.Stream()
     _lib.check(lib.zg_set_stream(stream.cuda_stream))
     run = lambda: _lib.check(lib.zg_gemm_bf16_nt(a.data_ptr(), b.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, int(gelu), int(out_bf16)))
-    for _ in range(400):  # the chip needs tens of milliseconds under load before its clocks settle
+    for _ in range(warm):  # the chip needs tens of milliseconds under load before its clocks settle
         run()
     torch.cuda.synchronize()
-    batches = []
-    for _ in range(5):  # five timed batches: the MEAN is the headline, the minimum is printed beside it
+    n_batches, batches = batches, []
+    for _ in range(n_batches):  # five timed batches: the MEAN is the headline, the minimum is printed beside it
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(iters):
@@ -34,8 +34,8 @@ def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50):
     flops = 2.0 * m * n * k
     return {"M": m, "N": n, "K": k, "us": round(us, 2), "us_min": round(us_min, 2), "tflops": round(flops / us / 1e6, 1),
             "mfma_frac_of_2.5PF": round(flops / us / 1e6 / PEAK_TF, 4), "mfma_frac_of_2.5PF_best_batch": round(flops / us_min / 1e6 / PEAK_TF, 4),
-            "timing": "mean of five batches of %d back-to-back launches (HIP events on the launch stream) after 400 warm-up launches; us_min = best batch" % iters,
-            "kernel": os.environ.get("ZGPT2_GEMM_KERNEL", "default (gemm_s4_kernel for 192-wide tiles, gemm_p8_kernel for 256-wide)"),
+            "timing": "mean of %d batches of %d back-to-back launches (HIP events on the launch stream) after %d warm-up launches; us_min = best batch" % (n_batches, iters, warm),
+            "kernel": os.environ.get("ZGPT2_GEMM_KERNEL", "default (gemm_s4_kernel for 192-wide tiles, gemm_p8_kernel for 256-wide)"), "stores": "write-through (sc1)",
             "gelu": gelu, "out": "bf16" if out_bf16 else "f32",
             "bytes_min": (m * k + n * k) * 2 + m * n * (2 if out_bf16 else 4)}
 

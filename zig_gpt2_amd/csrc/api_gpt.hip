@@ -67,6 +67,8 @@ struct zg_gpt {
     unsigned spin_limit;  // polls before a poller of a tagged hand-over gives up
     unsigned* fault;  // set by a poller of a tagged hand-over whose bounded wait ran out; checked wherever a call drains the stream
     unsigned long long *sk_tag, *part_tag;
+    size_t sk_tag_bytes, part_tag_bytes;
+    size_t epochs_since_clear;  // steps enqueued since the tagged words were last zeroed (note_steps)
     bool tags_on;
     // LayerNorm statistics of x by 16-column tile, written by the producers of x (GemvArgs.st_out / st_in)
     float* xst;
@@ -176,10 +178,11 @@ void carve(zg_gpt* g, char* base) {
     g->ap = (bf16_t*)P(E * 48);
     g->attn_cnt = (int*)P(8 * c.n_heads * 4);
     g->epoch = (unsigned*)P(256);
-    g->fault = (unsigned*)P(256);
     g->xst = (float*)P(((E + 15) / 16) * 8 * 2 * 4);
-    g->sk_tag = (unsigned long long*)P(((E + 15) / 16) * 4 * 128 * 8);
-    g->part_tag = (unsigned long long*)P(8 * c.n_heads * g->max_splits * kPartStride * 8);
+    g->sk_tag_bytes = ((E + 15) / 16) * 4 * 128 * 8;
+    g->part_tag_bytes = 8 * c.n_heads * g->max_splits * kPartStride * 8;
+    g->sk_tag = (unsigned long long*)P(g->sk_tag_bytes);
+    g->part_tag = (unsigned long long*)P(g->part_tag_bytes);
     g->sk_tiles = (int)((E + 15) / 16);
     g->sk_ws = (float*)P((size_t)g->sk_tiles * 4 * 128 * 4);
     g->sk_cnt = (int*)P((size_t)g->sk_tiles * 4 * 4);  // [tile][4]: the four-wave plane-fed kernel takes one ticket per wave
@@ -573,16 +576,30 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
 }
 
 // The tagged hand-overs of the lock-step batch poll with a bound; a poller that ran into it raised the fault word.  The
-// results of such a step are wrong, so the call that drains the stream fails (and clears the word for the next call).
-int check_fault(zg_gpt* g, hipStream_t s) {
+// results of such a step are wrong, so every entry point that drains the stream fails (and clears the word for the next
+// call).  The word lives in pinned host memory the kernels store to directly: reading it costs no copy and no second
+// synchronisation.  PRECONDITION: the stream has been drained since the steps in question.
+int check_fault(zg_gpt* g) {
     if (!g->tags_on) return ZG_OK;
-    unsigned f = 0;
-    ZG_HIP(hipMemcpyAsync(&f, g->fault, sizeof(f), hipMemcpyDeviceToHost, s));
-    ZG_HIP(hipStreamSynchronize(s));
-    if (f == 0) return ZG_OK;
-    (void)hipMemsetAsync(g->fault, 0, sizeof(unsigned), s);
-    set_error("a tagged hand-over of the decode step timed out (a workgroup waited 2^20 polls for its writers): results discarded");
+    volatile unsigned* f = g->fault;
+    if (*f == 0) return ZG_OK;
+    *f = 0;
+    set_error("a tagged hand-over of the decode step timed out (a workgroup waited %u polls for its writers): results discarded", g->spin_limit);
     return ZG_ERR_HIP;
+}
+
+// A tag is (epoch << 8 | launch id) in 32 bits: 24 bits of the step counter survive, and a slot that is only written at long
+// contexts (the high attention splits) could meet its own tag again 2^24 steps later — about an hour of decoding.  So the
+// host counts the steps it enqueues and zeroes the tagged words (tag 0 is never valid: launch ids start at 1) on the stream
+// every 2^23 of them, in front of the steps of the call that crosses the mark.
+int note_steps(zg_gpt* g, size_t n, hipStream_t s) {
+    if (!g->tags_on) return ZG_OK;
+    g->epochs_since_clear += n;
+    if (g->epochs_since_clear < ((size_t)1 << 23)) return ZG_OK;
+    g->epochs_since_clear = n;
+    ZG_HIP(hipMemsetAsync(g->sk_tag, 0, g->sk_tag_bytes, s));
+    ZG_HIP(hipMemsetAsync(g->part_tag, 0, g->part_tag_bytes, s));
+    return ZG_OK;
 }
 
 int env_int(const char* name, int dflt) {
@@ -898,7 +915,8 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     }
     g->h_ctrl = nullptr;
     g->h_ints = nullptr;
-    hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&g->h_ctrl), sizeof(StepCtrl), hipHostMallocDefault);
+    // (the control mirror and, 256 bytes behind it, the fault word of the tagged hand-overs: pinned, written by the kernels)
+    hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&g->h_ctrl), sizeof(StepCtrl) + 512, hipHostMallocDefault);
     if (he == hipSuccess)
         he = hipHostMalloc(reinterpret_cast<void**>(&g->h_ints), (batch * c.context_size + batch) * sizeof(int), hipHostMallocDefault);
     if (he != hipSuccess) {
@@ -907,7 +925,11 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         delete g;
         return hip_fail(he, "hipHostMalloc(control mirrors)", __FILE__, __LINE__);
     }
+    static_assert(sizeof(StepCtrl) <= 256, "the fault word sits 256 bytes behind the control mirror");
+    g->fault = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(g->h_ctrl) + 256);
+    *g->fault = 0;
     g->steps_enqueued = 0;
+    g->epochs_since_clear = 0;
     g->ln_folded = false;
     {   // decode steps per graph in the generate loop: a graph launch costs ~7 us of idle queue (124M: 224.8 us per token
         // with 1 step per graph, 220.4 with 2 / 4, 218.3 with 8, 219.5 with 16)
@@ -1044,6 +1066,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     g->h_ctrl->n_partials = g->lm_grid;
     ZG_HIP(hipMemcpyAsync(g->forced, g->h_ints, g->batch * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    ZG_TRY(note_steps(g, 1, s));
     ZG_TRY(run_step(g, compute_logits != 0, seq_len, s));
     if (logits_out) {
         ZG_HIP(hipMemcpyAsync(logits_out, g->logits, g->batch * V * sizeof(float),
@@ -1051,7 +1074,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     }
     // h_ints / h_ctrl are reused by the next call: drain before returning.
     ZG_HIP(hipStreamSynchronize(s));
-    return check_fault(g, s);
+    return check_fault(g);
 }
 
 int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t n_tokens, int compute_logits,
@@ -1143,7 +1166,7 @@ int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len) {
     ZG_HIP(hipMemcpyAsync(x_out, g->x, g->batch * g->cfg.n_embed * sizeof(float),
                           is_device_ptr(x_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
-    return ZG_OK;
+    return check_fault(g);
 }
 
 int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens,
@@ -1185,6 +1208,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     }
     ZG_TRY(ensure_ln_folded(g, s));
     if (!(g->flags & ZG_GPT_NO_GRAPH) && s != nullptr && g->graph_stream != s) ZG_TRY(capture_all(g, s));  // before the prefetcher starts its idle clock
+    ZG_TRY(note_steps(g, n_steps, s));
     ZG_TRY(pf_start(g, n_steps, s));
     int rs = ZG_OK;
     const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;
@@ -1226,7 +1250,7 @@ int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t 
     hipStream_t s = ctx().stream;
     ZG_HIP(hipMemcpyAsync(g->h_ints, g->out_tokens, B * C * sizeof(int), hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
-    ZG_TRY(check_fault(g, s));
+    ZG_TRY(check_fault(g));
     for (size_t b = 0; b < B; ++b)
         for (size_t i = 0; i < n_steps; ++i) out_tokens[b * n_steps + i] = (size_t)g->h_ints[b * C + i];
     return ZG_OK;
@@ -1247,6 +1271,7 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
     hipStream_t s = ctx().stream;
     ZG_HIP(hipStreamSynchronize(s));
     ZG_TRY(ensure_ln_folded(g, s));
+    ZG_TRY(note_steps(g, (size_t)iters, s));
     for (size_t b = 0; b < g->batch; ++b) g->h_ints[b] = (int)(b % g->cfg.vocab_size);
     g->h_ctrl->step = (int)seq_len - 1;
     g->h_ctrl->seq_len = (int)seq_len;
@@ -1280,7 +1305,7 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
     }
     for (int i = 0; i < 8; ++i) us_out[i] = (float)(acc[i] / iters);
     if (n_out >= 9) us_out[8] = (float)(null_us / iters);
-    return ZG_OK;
+    return check_fault(g);  // (every event above was synchronised: timings of a faulted step are not reported)
 }
 
 int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes) {
@@ -1298,6 +1323,7 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     }
     ZG_HIP(hipStreamSynchronize(s));
     ZG_TRY(ensure_ln_folded(g, s));
+    ZG_TRY(note_steps(g, (size_t)iters + 8, s));  // (one epoch per replay of the chain)
     g->h_ctrl->step = (int)T - 1;
     g->h_ctrl->seq_len = (int)T;
     g->h_ctrl->mode = 1;
@@ -1337,7 +1363,7 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     (void)hipGraphDestroy(graph);
     *avg_us = ms * 1000.0f / (float)(reps * chain);
     if (algorithmic_bytes) *algorithmic_bytes = bytes_tab[which];
-    return ZG_OK;
+    return check_fault(g);
 }
 
 int zg_debug_prefetch_stats(zg_gpt* g, unsigned* out, size_t n_out) {

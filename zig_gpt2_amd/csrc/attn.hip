@@ -110,12 +110,17 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, 
     // nsplit = the launched splits: every one of them publishes
     float r = o, lsum = l;
     if (nsplit > 1 && a.part_tag) {
-        // Tagged hand-over: splits 1.. store (value, tag) words and are done; split 0 polls them — one memory-side round
-        // trip behind the slowest split instead of the three of the ticket below (drain, ticket, read back).
+        // Tagged hand-over: every split but the LAST stores (value, tag) words and is done; the last split polls them — one
+        // memory-side round trip behind the slowest split instead of the three of the ticket below (drain, ticket, read back).
+        // The poller is the last split because a launch's workgroups are dispatched in block order (x, then y = split): the
+        // workgroups it waits for are placed BEFORE it, so it can never hold a slot that one of them needs — whatever the
+        // occupancy (CU masks, partitions, other resident kernels).  Arithmetic in split order, as the consumer-side merge.
         typedef unsigned long long u64;
         auto pack = [&](float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); };
-        u64* pt = a.part_tag + (((size_t)b * n_heads + h) * a.max_splits + split) * kPartStride;
-        if (split != 0) {
+        u64* pt0 = a.part_tag + ((size_t)b * n_heads + h) * a.max_splits * kPartStride;  // split 0 of this (sequence, head)
+        const int last = nsplit - 1;
+        if (split != last) {
+            u64* pt = pt0 + split * kPartStride;
             __hip_atomic_store(pt + lane, pack(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) {
                 __hip_atomic_store(pt + 64, pack(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -132,12 +137,12 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, 
             for (int spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int s = 1; s < MAXS; ++s) {  // surplus splits re-read the last valid one (weight 0 below)
-                    const u64* ps = pt + min(s, nsplit - 1) * kPartStride;
-                    vo[s - 1] = __hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vm[s - 1] = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vl[s - 1] = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (unsigned)(vo[s - 1] >> 32) == tag && (unsigned)(vm[s - 1] >> 32) == tag && (unsigned)(vl[s - 1] >> 32) == tag;
+                for (int s = 0; s < MAXS - 1; ++s) {  // splits 0 .. last - 1; surplus slots re-read the last of them (unused below)
+                    const u64* ps = pt0 + min(s, last - 1) * kPartStride;
+                    vo[s] = __hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vm[s] = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vl[s] = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(vo[s] >> 32) == tag && (unsigned)(vm[s] >> 32) == tag && (unsigned)(vl[s] >> 32) == tag;
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 if ((unsigned)spins >= a.spin_limit) {  // bounded: never hang the queue — and never pass silently
@@ -147,12 +152,12 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, 
                 __builtin_amdgcn_s_sleep(1);
             }
             float ms[MAXS], ls[MAXS], os[MAXS];
-            ms[0] = M; ls[0] = l; os[0] = o;
 #pragma unroll
-            for (int s = 1; s < MAXS; ++s) {
-                ms[s] = s < nsplit ? __uint_as_float((unsigned)vm[s - 1]) : -1e30f;
-                ls[s] = __uint_as_float((unsigned)vl[s - 1]);
-                os[s] = __uint_as_float((unsigned)vo[s - 1]);
+            for (int s = 0; s < MAXS; ++s) {  // slot s = split s: polled below `last`, this workgroup's own at `last`, weight 0 above
+                const bool polled = s < last && s < MAXS - 1;
+                ms[s] = polled ? __uint_as_float((unsigned)vm[s < MAXS - 1 ? s : 0]) : s == last ? M : -1e30f;
+                ls[s] = polled ? __uint_as_float((unsigned)vl[s < MAXS - 1 ? s : 0]) : l;
+                os[s] = polled ? __uint_as_float((unsigned)vo[s < MAXS - 1 ? s : 0]) : o;
             }
             mx = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
 #pragma unroll
@@ -161,30 +166,33 @@ __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, 
                 lsum = fmaf(w, ls[s], lsum);
                 r = fmaf(w, os[s], r);
             }
-        } else {  // long contexts: one split at a time, running maximum
-            float mrun = M;
-            r = o;
-            lsum = l;
-            for (int s = 1; s < nsplit; ++s) {
-                const u64* ps = pt + s * kPartStride;
-                u64 vo, vm, vl;
-                for (int spins = 0;; ++spins) {
-                    vo = __hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vm = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vl = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = (unsigned)(vo >> 32) == tag && (unsigned)(vm >> 32) == tag && (unsigned)(vl >> 32) == tag;
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                    if ((unsigned)spins >= a.spin_limit) {
-                        if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+        } else {  // long contexts: one split at a time, running maximum; this workgroup's own partial last
+            float mrun = -1e30f;
+            for (int s = 0; s <= last; ++s) {
+                float m_s = M, o_s = o, l_s = l;
+                if (s < last) {
+                    const u64* ps = pt0 + s * kPartStride;
+                    u64 vo, vm, vl;
+                    for (int spins = 0;; ++spins) {
+                        vo = __hip_atomic_load(ps + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vm = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vl = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool ok = (unsigned)(vo >> 32) == tag && (unsigned)(vm >> 32) == tag && (unsigned)(vl >> 32) == tag;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        if ((unsigned)spins >= a.spin_limit) {
+                            if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    m_s = __uint_as_float((unsigned)vm);
+                    o_s = __uint_as_float((unsigned)vo);
+                    l_s = __uint_as_float((unsigned)vl);
                 }
-                const float m_s = __uint_as_float((unsigned)vm);
                 const float mnew = fmaxf(mrun, m_s);
                 const float w0 = __expf(mrun - mnew), w1 = __expf(m_s - mnew);
-                r = fmaf(w1, __uint_as_float((unsigned)vo), r * w0);
-                lsum = fmaf(w1, __uint_as_float((unsigned)vl), lsum * w0);
+                r = fmaf(w1, o_s, r * w0);
+                lsum = fmaf(w1, l_s, lsum * w0);
                 mrun = mnew;
             }
         }

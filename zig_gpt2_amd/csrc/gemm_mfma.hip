@@ -576,7 +576,12 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
         return launch_gemm_ov(A, B, bias, C, M, N, pl, ldc, gelu, s);
     }
     g_last_gemm_kernel = 0;
-    if (force_s4 || ragged || (!force_p8 && bn == 192)) return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, 192, s);
+    // The four-wave kernel packs its arguments (gemm_s4_args_ok: lda / ldb < 65536, K < 16384 per plane, <= 6 plane pairs);
+    // a shape beyond that runs on the eight-wave kernel — unless it is ragged, which only the four-wave kernel stores.
+    const bool s4_ok = gemm_s4_args_ok(pl, ldc);
+    ZG_REQUIRE(s4_ok || !ragged, ZG_ERR_UNSUPPORTED, "gemm: a ragged output (N=%d, ldc=%d) with lda %d / ldb %d / K %d beyond the four-wave kernel", N,
+               ldc, pl.lda, pl.ldb, K);
+    if (s4_ok && (force_s4 || ragged || (!force_p8 && bn == 192))) return launch_gemm_s4(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, 192, s);
     return bn == 192 ? launch_p8_bn<192>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s)
                      : launch_p8_bn<256>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
 }

@@ -730,9 +730,8 @@ int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, 
     const int cus = cus_env > 0 ? cus_env : 256;
     const int grid = n_tiles < cus ? n_tiles : cus;
     const unsigned dbg = (unsigned)(getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
-    ZG_REQUIRE(pl.lda > 0 && pl.ldb > 0 && pl.lda < 65536 && pl.ldb < 65536 && ldc < (1 << 20) && pl.kpp < 256 && pl.npairs <= 6 && gw < 256 &&
-                   grid < 1024 && dbg < (1u << 22),
-               ZG_ERR_UNSUPPORTED, "gemm: lda %d / ldb %d / ldc %d / K beyond the packed kernel arguments", pl.lda, pl.ldb, ldc);
+    ZG_REQUIRE(gemm_s4_args_ok(pl, ldc) && gw < 256 && grid < 1024 && dbg < (1u << 22), ZG_ERR_UNSUPPORTED,
+               "gemm: lda %d / ldb %d / ldc %d / K beyond the packed kernel arguments", pl.lda, pl.ldb, ldc);
     unsigned pa2 = 0, pb2 = 0;
     for (int i = 0; i < pl.npairs; ++i) {
         pa2 |= ((pl.pa_bits >> (4 * i)) & 3u) << (2 * i);
@@ -777,6 +776,12 @@ int launch_s4_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, i
 }
 
 }  // namespace
+
+// what the 14 packed argument dwords of gemm_s4_kernel can express (the dispatcher sends anything else that is not ragged
+// to the eight-wave kernel, whose arguments are not packed; api_ops.hip keeps ragged Linears beyond it on the GEMV path)
+bool gemm_s4_args_ok(const GemmPlanes& pl, int ldc) {
+    return pl.lda > 0 && pl.ldb > 0 && pl.lda < 65536 && pl.ldb < 65536 && ldc < (1 << 20) && pl.kpp < 256 && pl.npairs <= 6;
+}
 
 int gemm_s4_stamps(unsigned long long* out, size_t n_words) {
     if (n_words > 1 + 4 * 256 + 16) n_words = 1 + 4 * 256 + 16;

@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(const bf16_t* __rest
 // producer of x wrote, or its share of x itself), the waves meet once, and each wave finishes ONE accumulator register
 // of the tile: lane (n = lane & 15, half = lane >> 4 < 2) of wave w owns output (m = 4 half + w, n).  K slices over
 // blockIdx.y (KSL > 1) combine per wave, without a workgroup barrier: by tagged data (slices 1.. store (value, tag)
-// words, slice 0 polls them and adds in slice order) or, without an epoch word, by a ticket on counter [tile][w] whose
+// words, the last slice polls them and adds in slice order) or, without an epoch word, by a ticket on counter [tile][w] whose
 // last arriver adds the slices in fixed order.
 // KP = 64-k pairs per wave (K <= 256 KP per slice).
 // ================================================================================================
@@ -1759,20 +1759,23 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
     for (int w = 0; w < 4; ++w) y += s_part[(w * 32 + (lane & 31)) * 4 + wave];
     bool run = true;
     if (KSL > 1 && a.sk_tag != nullptr) {
-        // Tagged hand-over: slices 1.. store (value, tag) words and are done; slice 0 polls them and adds in slice order —
-        // one memory-side round trip behind the slowest slice instead of the three of the ticket below.
+        // Tagged hand-over: every slice but the LAST stores (value, tag) words and is done; the last slice polls them and adds
+        // in slice order — one memory-side round trip behind the slowest slice instead of the three of the ticket below.
+        // The poller is the last slice (blockIdx.y = KSL - 1): workgroups are dispatched in block order, so the writers it
+        // waits for are placed before it and it can never hold a slot that one of them needs, whatever the occupancy.
         typedef unsigned long long u64;
-        u64* slot = a.sk_tag + ((size_t)tile * KSL + blockIdx.y) * 128 + wave * 32 + (lane & 31);
-        if (blockIdx.y != 0) {
-            if (lane < 32) __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64* slot0 = a.sk_tag + (size_t)tile * KSL * 128 + wave * 32 + (lane & 31);  // slice 0 of this tile
+        if ((int)blockIdx.y != KSL - 1) {
+            if (lane < 32)
+                __hip_atomic_store(slot0 + blockIdx.y * 128, ((u64)tag << 32) | (u64)__float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             run = false;
         } else {
             u64 v[KSL];
             for (int spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int ks = 1; ks < KSL; ++ks) {
-                    v[ks] = __hip_atomic_load(slot + ks * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int ks = 0; ks < KSL - 1; ++ks) {
+                    v[ks] = __hip_atomic_load(slot0 + ks * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = ok && (unsigned)(v[ks] >> 32) == tag;
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
@@ -1782,8 +1785,10 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+            float ysum = __uint_as_float((unsigned)v[0]);
 #pragma unroll
-            for (int ks = 1; ks < KSL; ++ks) y += __uint_as_float((unsigned)v[ks]);
+            for (int ks = 1; ks < KSL - 1; ++ks) ysum += __uint_as_float((unsigned)v[ks]);
+            y = ysum + y;  // slice order 0, 1, .., KSL - 1
         }
     } else if constexpr (KSL > 1) {
         // Publish with write-through (agent-scope relaxed atomic = sc1) stores, drain them, take a ticket; the last arriver

@@ -253,10 +253,23 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
                 rd_a(kk1, p1, aq[(g + 1) & 1]);
                 n_next += 2;
             }
-            if (n_next == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if (n_next == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-            else if (n_next == 2 + NJ && NJ == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            // The wait names group g's fragments as read-write operands: for the compiler they are ready straight behind the
+            // read statements, and only an operand tie keeps a copy, coalesce or spill of those registers from being placed in
+            // front of the wait (sched_barrier pins instruction order, not what register allocation inserts).
+#define ZG_WAIT_FRAGS(N)                                                                                                                          \
+    do {                                                                                                                                          \
+        if constexpr (NJ == 2)                                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(aq[g & 1][0]), "+v"(aq[g & 1][1]), "+v"(bq[kk & 1][0]), "+v"(bq[kk & 1][NJ - 1])::"memory"); \
+        else                                                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                              \
+                         : "+v"(aq[g & 1][0]), "+v"(aq[g & 1][1]), "+v"(bq[kk & 1][0]), "+v"(bq[kk & 1][1]), "+v"(bq[kk & 1][NJ > 2 ? 2 : 0]),       \
+                           "+v"(bq[kk & 1][NJ - 1])::"memory");                                                                                   \
+    } while (0)
+            if (n_next == 0) ZG_WAIT_FRAGS(0);
+            else if (n_next == 2) ZG_WAIT_FRAGS(2);
+            else if (n_next == 2 + NJ && NJ == 2) ZG_WAIT_FRAGS(4);
+            else ZG_WAIT_FRAGS(6);
+#undef ZG_WAIT_FRAGS
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)

@@ -175,6 +175,7 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
                        int ldc, bool gelu, bool out_bf16, hipStream_t s);
 int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
                    bool gelu, bool out_bf16, int bn, hipStream_t s);  // gemm_s4.hip
+bool gemm_s4_args_ok(const GemmPlanes& pl, int ldc);            // the bounds of gemm_s4_kernel's packed arguments
 int gemm_s4_stamps(unsigned long long* out, size_t n_words);  // diagnostic (ZGPT2_GEMM_DBG bit 256)
 // bf16 result, 192-wide tiles, the epilogue of a tile under the next tile's main loop (gemm_ov.hip)
 bool gemm_ov_args_ok(int M, const GemmPlanes& pl, int ldc);
