@@ -70,6 +70,19 @@ struct zg_gpt {
     size_t sk_tag_bytes, part_tag_bytes;
     size_t epochs_since_clear;  // steps enqueued since the tagged words were last zeroed (note_steps)
     bool tags_on;
+    // Two-stream decode of ONE sequence ("dual"): the kernels of a step are dealt to two hipGraphs on two streams — A: embed,
+    // then per Block ln_1 + c_attn, attention, merge + c_proj (the last Block whole, and lm_head); B: ln_2 + c_fc and mlp c_proj
+    // of every Block but the last — and the residual stream crosses between them as (value, tag) granules xg (GemvArgs.xg): the
+    // kernel on the other stream is resident, its weights in flight, while its producer still runs, instead of starting behind
+    // a kernel boundary (tools/microbench/two_graph_probe.hip: 4.31 -> 3.28 us per dependent 768 x 768 stage).
+    // B is itself two streams: ln_2 + c_fc on one, mlp c_proj on the other, gelu(c_fc) crossing as granules h4g.
+    bool dual_on;
+    int dual_parts;           // 2: mlp c_proj stays behind c_fc on the B stream (plain h4); 3: it has its own stream
+    unsigned long long *xg, *h4g;  // [E], [4 E] granules
+    unsigned* epoch2;         // step counters of the graphs: [0] A (advanced by the embed kernel), [64] B, [128] C (by bump kernels)
+    hipStream_t s2, s3;
+    hipEvent_t ev_fork, ev_join, ev_join3;
+    std::vector<hipGraphExec_t> graphs_b, graphs_kb, graphs_c, graphs_kc;  // the B / C parts of graphs / graphs_k
     // LayerNorm statistics of x by 16-column tile, written by the producers of x (GemvArgs.st_out / st_in)
     float* xst;
     bool st_on;
@@ -85,6 +98,16 @@ struct zg_gpt {
     std::vector<hipGraphExec_t> graphs_k;  // per bucket: graph_steps consecutive steps with lm_head in one graph (generate loop)
     size_t graph_steps;
     hipStream_t graph_stream;
+    // whole-prompt passes replayed as graphs: one per (prompt length, last Block in full) seen twice — the ~75 launches of a
+    // prefill cost ~9 us each as synchronous host calls (0.75 ms at 64 tokens), ~1.5 us from a graph.  The first pass of a
+    // length runs eagerly (its launchers raise kernel attributes once, which does not belong inside a capture), the second
+    // captures; at most kMaxPrefillGraphs are kept.
+    struct PfGraph {
+        size_t P;
+        bool full, seen_only;
+        hipGraphExec_t exec;
+    };
+    std::vector<PfGraph> pf_graphs;
     size_t steps_enqueued;
     bool ln_folded;  // c2 / c3 of every layer match the weights currently in the arena
     // side-stream L2 prefetcher of the decode chain (prefetch.hip); runs during zg_gpt_generate_enqueue only
@@ -179,6 +202,9 @@ void carve(zg_gpt* g, char* base) {
     g->attn_cnt = (int*)P(8 * c.n_heads * 4);
     g->epoch = (unsigned*)P(256);
     g->xst = (float*)P(((E + 15) / 16) * 8 * 2 * 4);
+    g->xg = (unsigned long long*)P(E * 8);
+    g->h4g = (unsigned long long*)P(4 * E * 8);
+    g->epoch2 = (unsigned*)P(1024);
     g->sk_tag_bytes = ((E + 15) / 16) * 4 * 128 * 8;
     g->part_tag_bytes = 8 * c.n_heads * g->max_splits * kPartStride * 8;
     g->sk_tag = (unsigned long long*)P(g->sk_tag_bytes);
@@ -353,17 +379,42 @@ int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
 // rec != nullptr: nothing is launched; the step's launches are described for the prefetcher instead (emit_gemv).
 // salt >= 0 (measurement chains of one kernel class): launch ids of the tagged hand-overs by chain position instead of by
 // layer, so that consecutive launches of the chain never find each other's tags.
+int env_int(const char* name, int dflt);
+
+// part (two-stream decode, zg_gpt.dual_on): -1 = the whole step on one stream, x as plain fp32 (also every measurement
+// path); 0 = the A half; 1 = the B half.  In the halves x crosses the streams as granules: writer ids 1 (embed),
+// 2 + 2 l (merge + c_proj of Block l), 3 + 2 l (mlp c_proj of Block l); the last Block runs whole on A with plain x.
 int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1, size_t only_layer = 0,
-                 std::vector<PfJob>* rec = nullptr, int salt = -1) {
-    const size_t E = g->cfg.n_embed;
+                 std::vector<PfJob>* rec = nullptr, int salt = -1, int part = -1) {
+    const size_t E = g->cfg.n_embed, L = g->cfg.n_layer;
     auto launch_id = [&](size_t l, int k) { return (unsigned)(salt >= 0 ? 1 + (2 * salt + k) % 254 : 2 * (int)l + 1 + k); };
+    const bool dual = part >= 0;
+    auto in_part = [&](size_t l, int k) {  // does kernel class k of Block l belong to this call?
+        if (!dual) return true;
+        const int owner = (k == 4 && l + 1 < L) ? 1 : (k == 5 && l + 1 < L) ? g->dual_parts - 1 : 0;
+        return owner == part;
+    };
+    auto xg_common = [&](GemvArgs& a) {
+        a.xg = g->xg;
+        a.epoch2 = g->epoch2 + 64 * part;
+        a.fault = g->fault;
+        a.spin_limit = g->spin_limit;
+    };
     ZG_TRY(prof_mark(prof, -1, s));
     if (rec) rec->push_back(PfJob{});
-    else if (only < 0 || only == 0) ZG_TRY(launch_embed_step(embed_args(g, only == 0 ? 3 : 0), s));  // main.zig:179-183
+    else if (part >= 1) ZG_TRY(launch_epoch_bump(g->epoch2 + 64 * part, s));  // the B / C parts count the same steps as A
+    else if (only < 0 || only == 0) {
+        EmbedArgs e = embed_args(g, only == 0 ? 3 : 0);  // main.zig:179-183
+        if (dual) {
+            e.xg = g->xg;
+            e.epoch2 = g->epoch2;
+        }
+        ZG_TRY(launch_embed_step(e, s));
+    }
     ZG_TRY(prof_mark(prof, 0, s));
     for (size_t l = (only < 0 ? 0 : only_layer); l < (only < 0 ? g->cfg.n_layer : only_layer + 1); ++l) {
         const zg_layer& y = g->layers[l];
-        if (only < 0 || only == 1) {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
+        if ((only < 0 || only == 1) && in_part(l, 1)) {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
             GemvArgs a = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * E, E, t_hi);
             a.prologue = PRO_LAYERNORM;
             a.x = g->x;
@@ -378,11 +429,16 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.q = g->q;
             a.k_cache = y.k_cache;
             a.v_cache = y.v_cache;
+            if (dual) {  // x from the embed kernel (same stream: complete) or from the B half's mlp c_proj of the Block before
+                xg_common(a);
+                a.xin_id = l == 0 ? 0u : (unsigned)(3 + 2 * (l - 1));
+                a.xout_id = (unsigned)env_int("ZGPT2_DUAL_SLEEP", 4);
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 1));
             ZG_TRY(prof_mark(prof, 1, s));
         }
-        if (only < 0 || only == 2) {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
+        if ((only < 0 || only == 2) && in_part(l, 2)) {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
             AttnArgs a{};
             a.q = g->q;
             a.k = y.k_cache;
@@ -425,7 +481,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 ZG_TRY(launch_attn_decode(a, s));
             ZG_TRY(prof_mark(prof, 2, s));
         }
-        if (only < 0 || only == 3) {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
+        if ((only < 0 || only == 3) && in_part(l, 3)) {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
             GemvArgs a = base_gemv(g, y.c_proj_w, y.c_proj_b, E, E, t_hi);
             a.prologue = PRO_ATTN_MERGE;
             a.part = g->part;
@@ -441,11 +497,16 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 a.pl_g = y.ln_2_g;
                 a.st_out = g->st_on ? g->xst : nullptr;
             }
+            if (dual) {  // residual from the granules (complete: this Block's c_attn saw every tag); output to the B half
+                xg_common(a);
+                a.xg_resid = 1;
+                a.xout_id = l + 1 < L ? (unsigned)(2 + 2 * l) : 0u;  // (the last Block continues on this stream: plain x)
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 3));
             ZG_TRY(prof_mark(prof, 3, s));
         }
-        if (only < 0 || only == 4) {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
+        if ((only < 0 || only == 4) && in_part(l, 4)) {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
             GemvArgs a = base_gemv(g, y.c_fc_w, y.c_fc_b, 4 * E, E, t_hi);
             a.prologue = PRO_LAYERNORM;
             a.x = g->x;
@@ -463,11 +524,20 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 a.pl_out = g->hp;
                 a.y = nullptr;
             }
+            if (part == 1) {  // x from the A part's merge + c_proj of this Block; gelu(c_fc) to the C part as granules
+                xg_common(a);
+                a.xin_id = (unsigned)(2 + 2 * l);
+                a.xout_id = (unsigned)env_int("ZGPT2_DUAL_SLEEP", 4);
+                if (g->dual_parts == 3) {
+                    a.yg = g->h4g;
+                    a.yout_id = (unsigned)(1 + l);
+                }
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 4));
             ZG_TRY(prof_mark(prof, 4, s));
         }
-        if (only < 0 || only == 5) {   // mlp c_proj + residual: main.zig:81, :142-145
+        if ((only < 0 || only == 5) && in_part(l, 5)) {   // mlp c_proj + residual: main.zig:81, :142-145
             GemvArgs a = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, E, 4 * E, t_hi);
             a.prologue = PRO_NONE;
             a.x = g->h4;
@@ -492,12 +562,21 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                     a.st_out = g->st_on ? g->xst : nullptr;
                 }
             }
+            if (part >= 1) {  // input from the B part's c_fc; residual from the granules (that c_fc saw every tag); output to A
+                xg_common(a);
+                if (g->dual_parts == 3) {
+                    a.in_g = g->h4g;
+                    a.xin_id = (unsigned)(1 + l);
+                }
+                a.xg_resid = 1;
+                a.xout_id = (unsigned)(3 + 2 * l);
+            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 5));
             ZG_TRY(prof_mark(prof, 5, s));
         }
     }
-    if (with_logits && (only < 0 || only == 6)) {
+    if (with_logits && (only < 0 || only == 6) && part <= 0) {
         ZG_TRY(enqueue_lm_head(g, s, rec));
         ZG_TRY(prof_mark(prof, 6, s));
     }
@@ -546,7 +625,41 @@ int enqueue_prefill_f32(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s
     return ZG_OK;
 }
 
+int enqueue_prefill_eager(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s);
+
+constexpr size_t kMaxPrefillGraphs = 16;
 int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
+    static const bool no_graph = getenv("ZGPT2_PREFILL_NO_GRAPH") != nullptr;
+    if (no_graph || (g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_prefill_eager(g, P, last_block_full, s);
+    if (g->graph_stream != s && !g->pf_graphs.empty()) {  // captured for another stream: start over
+        for (auto& e : g->pf_graphs)
+            if (e.exec) (void)hipGraphExecDestroy(e.exec);
+        g->pf_graphs.clear();
+    }
+    for (auto& e : g->pf_graphs)
+        if (e.P == P && e.full == last_block_full) {
+            if (e.seen_only) {  // second pass of this length: capture it
+                hipGraph_t graph = nullptr;
+                ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int st = enqueue_prefill_eager(g, P, last_block_full, s);
+                const hipError_t ce = hipStreamEndCapture(s, &graph);
+                if (st != ZG_OK || ce != hipSuccess) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    if (st != ZG_OK) return st;
+                    ZG_HIP(ce);
+                }
+                ZG_HIP(hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0));
+                ZG_HIP(hipGraphDestroy(graph));
+                e.seen_only = false;
+            }
+            ZG_HIP(hipGraphLaunch(e.exec, s));
+            return ZG_OK;
+        }
+    if (g->pf_graphs.size() < kMaxPrefillGraphs) g->pf_graphs.push_back(zg_gpt::PfGraph{P, last_block_full, true, nullptr});
+    return enqueue_prefill_eager(g, P, last_block_full, s);
+}
+
+int enqueue_prefill_eager(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
     if (g->wt == WT_F32) return enqueue_prefill_f32(g, P, last_block_full, s);
     const int np = (g->flags & ZG_GPT_PREFILL_2PLANE) ? 2 : kSplit;
     const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
@@ -580,10 +693,19 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
 // call).  The word lives in pinned host memory the kernels store to directly: reading it costs no copy and no second
 // synchronisation.  PRECONDITION: the stream has been drained since the steps in question.
 int check_fault(zg_gpt* g) {
-    if (!g->tags_on) return ZG_OK;
+    if (!g->tags_on && !g->dual_on) return ZG_OK;
     volatile unsigned* f = g->fault;
     if (*f == 0) return ZG_OK;
     *f = 0;
+    if (g->dual_on && getenv("ZGPT2_DUAL_DEBUG")) {
+        unsigned ep[128];
+        unsigned long long xs[8];
+        (void)hipMemcpy(ep, g->epoch2, 512, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(xs, g->xg, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "dual debug: epochA %u epochB %u; xg tags:", ep[0], ep[64]);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %x", (unsigned)(xs[i] >> 32));
+        fprintf(stderr, "\n");
+    }
     set_error("a tagged hand-over of the decode step timed out (a workgroup waited %u polls for its writers): results discarded", g->spin_limit);
     return ZG_ERR_HIP;
 }
@@ -619,6 +741,9 @@ int setup_prefetcher(zg_gpt* g) {
     const bool small = g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
     const int want = env_int("ZGPT2_PREFETCH", small ? 1 : 0);
     if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || ctx().stream == nullptr) return ZG_OK;
+    // the two-stream decode overlaps a kernel's weight fetch with its predecessor itself (and its launches do not pass the
+    // one progress counter the prefetcher follows in order)
+    if (g->dual_on && !env_int("ZGPT2_DUAL_PREFETCH", 0)) return ZG_OK;
     if (g->pf_njobs > 255) return ZG_OK;  // the progress word counts launches in 8 bits (n_layer >= 51): no prefetcher, not an error
     std::vector<PfJob> jobs;
     ZG_TRY(enqueue_step(g, true, (int)g->cfg.context_size, nullptr, nullptr, -1, 0, &jobs));
@@ -709,7 +834,7 @@ size_t prefill_min() {
 }
 
 void drop_graphs(zg_gpt* g) {
-    for (auto* v : {&g->graphs, &g->graphs_k})
+    for (auto* v : {&g->graphs, &g->graphs_k, &g->graphs_b, &g->graphs_kb, &g->graphs_c, &g->graphs_kc})
         for (auto& e : *v)
             if (e) {
                 (void)hipGraphExecDestroy(e);
@@ -719,42 +844,73 @@ void drop_graphs(zg_gpt* g) {
 
 // Run one decode step at sequence length seq_len: replay the graph of its bucket (capturing it on
 // first use), or launch eagerly when graphs are disabled / the stream cannot be captured.
-int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
-    const size_t seq_len = (idx / 2 + 1) * 64;  // any length of the bucket: only its upper bound is baked in
-    const bool with_logits = idx & 1;
-    if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
-    if (g->graphs[idx]) return ZG_OK;
+// n_steps consecutive steps (part as enqueue_step) captured on stream cs into *out
+int capture_steps(zg_gpt* g, hipGraphExec_t* out, bool with_logits, int t_hi, size_t n_steps, int part, hipStream_t cs) {
     hipGraph_t graph = nullptr;
-    ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    const int st = enqueue_step(g, with_logits, bucket_t_hi(g, seq_len), s);
-    hipError_t e = hipStreamEndCapture(s, &graph);
+    ZG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int st = ZG_OK;
+    for (size_t i = 0; i < n_steps && st == ZG_OK; ++i) st = enqueue_step(g, with_logits, t_hi, cs, nullptr, -1, 0, nullptr, -1, part);
+    hipError_t e = hipStreamEndCapture(cs, &graph);
     if (st != ZG_OK) {
         if (graph) (void)hipGraphDestroy(graph);
         return st;
     }
     ZG_HIP(e);
-    ZG_HIP(hipGraphInstantiate(&g->graphs[idx], graph, nullptr, nullptr, 0));
+    ZG_HIP(hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
     ZG_HIP(hipGraphDestroy(graph));
     return ZG_OK;
+}
+
+int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
+    const size_t seq_len = (idx / 2 + 1) * 64;  // any length of the bucket: only its upper bound is baked in
+    const bool with_logits = idx & 1;
+    if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
+    if (g->graphs_b.size() <= idx) g->graphs_b.resize(idx + 1, nullptr);
+    if (g->graphs_c.size() <= idx) g->graphs_c.resize(idx + 1, nullptr);
+    if (g->graphs[idx]) return ZG_OK;
+    const int t_hi = bucket_t_hi(g, seq_len);
+    if (g->dual_on) ZG_TRY(capture_steps(g, &g->graphs_b[idx], with_logits, t_hi, 1, 1, g->s2));
+    if (g->dual_on && g->dual_parts == 3) ZG_TRY(capture_steps(g, &g->graphs_c[idx], with_logits, t_hi, 1, 2, g->s3));
+    return capture_steps(g, &g->graphs[idx], with_logits, t_hi, 1, g->dual_on ? 0 : -1, s);
 }
 
 // graph_steps consecutive decode steps (all with lm_head, all in 64-position bucket b) as ONE graph: the position lives
 // in device memory, so the same kernels simply repeat; saves the gap between graph launches in the generate loop.
 int capture_multi(zg_gpt* g, size_t b, hipStream_t s) {
     if (g->graphs_k.size() <= b) g->graphs_k.resize(b + 1, nullptr);
+    if (g->graphs_kb.size() <= b) g->graphs_kb.resize(b + 1, nullptr);
+    if (g->graphs_kc.size() <= b) g->graphs_kc.resize(b + 1, nullptr);
     if (g->graphs_k[b]) return ZG_OK;
-    hipGraph_t graph = nullptr;
-    ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int st = ZG_OK;
-    for (size_t i = 0; i < g->graph_steps && st == ZG_OK; ++i) st = enqueue_step(g, true, bucket_t_hi(g, (b + 1) * 64), s);
-    hipError_t e = hipStreamEndCapture(s, &graph);
-    if (st != ZG_OK) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return st;
+    const int t_hi = bucket_t_hi(g, (b + 1) * 64);
+    if (g->dual_on) ZG_TRY(capture_steps(g, &g->graphs_kb[b], true, t_hi, g->graph_steps, 1, g->s2));
+    if (g->dual_on && g->dual_parts == 3) ZG_TRY(capture_steps(g, &g->graphs_kc[b], true, t_hi, g->graph_steps, 2, g->s3));
+    return capture_steps(g, &g->graphs_k[b], true, t_hi, g->graph_steps, g->dual_on ? 0 : -1, s);
+}
+
+// Two-stream decode: the B stream starts behind everything enqueued on s so far (LayerNorm folds, prefill), and s continues
+// behind the B half of the steps launched since — so that draining s drains both.
+int dual_fork(zg_gpt* g, hipStream_t s) {
+    if (!g->dual_on) return ZG_OK;
+    ZG_HIP(hipEventRecord(g->ev_fork, s));
+    ZG_HIP(hipStreamWaitEvent(g->s2, g->ev_fork, 0));
+    ZG_HIP(hipStreamWaitEvent(g->s3, g->ev_fork, 0));
+    return ZG_OK;
+}
+int dual_join(zg_gpt* g, hipStream_t s) {
+    if (!g->dual_on) return ZG_OK;
+    ZG_HIP(hipEventRecord(g->ev_join, g->s2));
+    ZG_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
+    ZG_HIP(hipEventRecord(g->ev_join3, g->s3));
+    ZG_HIP(hipStreamWaitEvent(s, g->ev_join3, 0));
+    return ZG_OK;
+}
+// launch a captured step (or steps) on s — and its B half on the second stream
+int launch_graphs(zg_gpt* g, hipGraphExec_t a, hipGraphExec_t b, hipGraphExec_t c, hipStream_t s) {
+    ZG_HIP(hipGraphLaunch(a, s));
+    if (g->dual_on) {
+        ZG_HIP(hipGraphLaunch(b, g->s2));
+        if (g->dual_parts == 3) ZG_HIP(hipGraphLaunch(c, g->s3));
     }
-    ZG_HIP(e);
-    ZG_HIP(hipGraphInstantiate(&g->graphs_k[b], graph, nullptr, nullptr, 0));
-    ZG_HIP(hipGraphDestroy(graph));
     return ZG_OK;
 }
 
@@ -783,8 +939,7 @@ int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
     if (g->graph_stream != s) ZG_TRY(capture_all(g, s));  // the caller switched streams after zg_gpt_create
     const size_t idx = ((seq_len + 63) / 64 - 1) * 2 + (with_logits ? 1 : 0);
     ZG_TRY(capture_bucket(g, idx, s));  // no-op: captured at create
-    ZG_HIP(hipGraphLaunch(g->graphs[idx], s));
-    return ZG_OK;
+    return launch_graphs(g, g->graphs[idx], g->graphs_b[idx], g->graphs_c[idx], s);
 }
 
 int upload_f32(const float* src, size_t n, void* dst, bool as_bf16, hipStream_t s) {
@@ -884,6 +1039,52 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     }
     g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
     g->spin_limit = (unsigned)env_int("ZGPT2_TAG_SPIN_LIMIT", 1 << 20);
+    // Two-stream decode: one sequence, bf16 weights, graphs, at least two Blocks, and every kernel on the x edges one that
+    // knows granules (K-split kernels: n_embed <= 1024 for the head-merging c_proj, 4 n_embed >= 2048 for mlp c_proj)
+    g->dual_on = false;
+    g->s2 = g->s3 = nullptr;
+    g->ev_fork = g->ev_join = g->ev_join3 = nullptr;
+    if (batch == 1 && g->wt == WT_BF16 && c.n_layer >= 2 && c.n_layer <= 120 && !(flags & ZG_GPT_NO_GRAPH) && ctx().stream != nullptr &&
+        env_int("ZGPT2_DUAL", 0) && !env_int("ZGPT2_NO_DUAL", 0)) {  // measured at parity with the side-stream prefetcher: opt-in
+        const zg_layer& y = g->layers[0];
+        const int t_top = (int)c.context_size;
+        GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, t_top);
+        a1.prologue = PRO_LAYERNORM;
+        a1.ln_c2 = y.c_attn_c2;
+        a1.ln_c3 = y.c_attn_c3;
+        a1.epilogue = EPI_QKV;
+        GemvArgs a4 = a1;
+        a4.N = (int)(4 * c.n_embed);
+        a4.ln_c2 = y.c_fc_c2;
+        a4.ln_c3 = y.c_fc_c3;
+        a4.epilogue = EPI_GELU;
+        GemvArgs a3 = base_gemv(g, y.c_proj_w, y.c_proj_b, c.n_embed, c.n_embed, t_top);
+        a3.prologue = PRO_ATTN_MERGE;
+        a3.epilogue = EPI_RESIDUAL;
+        GemvArgs a5 = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, c.n_embed, 4 * c.n_embed, t_top);
+        a5.prologue = PRO_NONE;
+        a5.epilogue = EPI_RESIDUAL;
+        g->dual_on = gemv_xg_ok(a1, g->wt) && gemv_xg_ok(a3, g->wt) && gemv_xg_ok(a4, g->wt) && gemv_xg_ok(a5, g->wt);
+    }
+    if (g->dual_on) {
+        // The three streams must sit on three different HARDWARE queues: two HIP streams that share one (the runtime deals its
+        // few queues round robin) execute in submission order, and a polling kernel queued in front of its producer never
+        // sees it run.  Streams of different priorities never share a queue: B runs above, C below the caller's stream.
+        int prio_lo = 0, prio_hi = 0;
+        hipError_t he2 = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        g->dual_parts = env_int("ZGPT2_DUAL_PARTS", 2) == 3 ? 3 : 2;
+        const int pswap = env_int("ZGPT2_DUAL_PRIO", 0);  // A/B: 0 = B high / C low, 1 = B low / C high
+        if (he2 == hipSuccess) he2 = hipStreamCreateWithPriority(&g->s2, hipStreamNonBlocking, pswap ? prio_lo : prio_hi);
+        if (he2 == hipSuccess) he2 = hipStreamCreateWithPriority(&g->s3, hipStreamNonBlocking, pswap ? prio_hi : prio_lo);
+        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
+        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
+        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_join3, hipEventDisableTiming);
+        if (he2 == hipSuccess) he2 = hipMemsetAsync(g->epoch2, 0, 1024, ctx().stream);
+        if (he2 == hipSuccess) he2 = hipMemsetAsync(g->xg, 0, c.n_embed * 8, ctx().stream);
+        if (he2 == hipSuccess) he2 = hipMemsetAsync(g->h4g, 0, 4 * c.n_embed * 8, ctx().stream);
+        if (he2 == hipSuccess) he2 = hipStreamSynchronize(ctx().stream);
+        if (he2 != hipSuccess) g->dual_on = false;  // (the single-stream step is always available)
+    }
     g->st_on = false;
     if (g->pl_on && !env_int("ZGPT2_NO_TILE_STATS", 0) && c.n_embed % 16 == 0 && c.n_embed / 16 <= 128) {
         // every producer and consumer of x must be the four-wave kernel
@@ -956,8 +1157,17 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
 int zg_gpt_destroy(zg_gpt* g) {
     if (!g) return ZG_OK;
     (void)hipStreamSynchronize(ctx().stream);
+    if (g->s2) (void)hipStreamSynchronize(g->s2);
+    if (g->s3) (void)hipStreamSynchronize(g->s3);
     drop_prefetcher(g);
     drop_graphs(g);
+    for (auto& e : g->pf_graphs)
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
+    if (g->s2) (void)hipStreamDestroy(g->s2);
+    if (g->s3) (void)hipStreamDestroy(g->s3);
     (void)hipFree(g->arena);
     (void)hipHostFree(g->h_ctrl);
     (void)hipHostFree(g->h_ints);
@@ -1067,7 +1277,10 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     ZG_HIP(hipMemcpyAsync(g->forced, g->h_ints, g->batch * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
     ZG_TRY(note_steps(g, 1, s));
+    ZG_TRY(ensure_ln_folded(g, s));
+    ZG_TRY(dual_fork(g, s));
     ZG_TRY(run_step(g, compute_logits != 0, seq_len, s));
+    ZG_TRY(dual_join(g, s));
     if (logits_out) {
         ZG_HIP(hipMemcpyAsync(logits_out, g->logits, g->batch * V * sizeof(float),
                               is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -1209,6 +1422,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_TRY(ensure_ln_folded(g, s));
     if (!(g->flags & ZG_GPT_NO_GRAPH) && s != nullptr && g->graph_stream != s) ZG_TRY(capture_all(g, s));  // before the prefetcher starts its idle clock
     ZG_TRY(note_steps(g, n_steps, s));
+    ZG_TRY(dual_fork(g, s));
     ZG_TRY(pf_start(g, n_steps, s));
     int rs = ZG_OK;
     const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;
@@ -1225,10 +1439,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
             if (g->graph_stream != s) rs = capture_all(g, s);
             const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
             if (rs == ZG_OK) rs = capture_multi(g, b, s);
-            if (rs == ZG_OK) {
-                const hipError_t le = hipGraphLaunch(g->graphs_k[b], s);
-                if (le != hipSuccess) rs = hip_fail(le, "hipGraphLaunch", __FILE__, __LINE__);
-            }
+            if (rs == ZG_OK) rs = launch_graphs(g, g->graphs_k[b], g->graphs_kb[b], g->graphs_kc[b], s);
             st += K;
         } else {
             rs = run_step(g, st >= min_prompt, st + 1, s);
@@ -1236,6 +1447,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
         }
     }
     ZG_TRY(pf_stop(g, s));  // also after a failed launch: the prefetcher must not wait for steps that never come
+    ZG_TRY(dual_join(g, s));
     ZG_TRY(rs);
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
     g->steps_enqueued = n_steps;
