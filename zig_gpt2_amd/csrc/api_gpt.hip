@@ -98,16 +98,6 @@ struct zg_gpt {
     std::vector<hipGraphExec_t> graphs_k;  // per bucket: graph_steps consecutive steps with lm_head in one graph (generate loop)
     size_t graph_steps;
     hipStream_t graph_stream;
-    // whole-prompt passes replayed as graphs: one per (prompt length, last Block in full) seen twice — the ~75 launches of a
-    // prefill cost ~9 us each as synchronous host calls (0.75 ms at 64 tokens), ~1.5 us from a graph.  The first pass of a
-    // length runs eagerly (its launchers raise kernel attributes once, which does not belong inside a capture), the second
-    // captures; at most kMaxPrefillGraphs are kept.
-    struct PfGraph {
-        size_t P;
-        bool full, seen_only;
-        hipGraphExec_t exec;
-    };
-    std::vector<PfGraph> pf_graphs;
     size_t steps_enqueued;
     bool ln_folded;  // c2 / c3 of every layer match the weights currently in the arena
     // side-stream L2 prefetcher of the decode chain (prefetch.hip); runs during zg_gpt_generate_enqueue only
@@ -625,41 +615,10 @@ int enqueue_prefill_f32(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s
     return ZG_OK;
 }
 
-int enqueue_prefill_eager(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s);
-
-constexpr size_t kMaxPrefillGraphs = 16;
+// (Measured and dropped in round 4: replaying this pass from a hipGraph per prompt length.  0.844 against 0.749 ms at 64
+// tokens, 1.645 against 1.553 ms at 1023 — the ~10 us a launch costs here is the kernels' own latency at these sizes, not host
+// overhead, and a graph launch adds its own ~10 us; profiles/round4_prefill_graph.jsonl.)
 int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
-    static const bool no_graph = getenv("ZGPT2_PREFILL_NO_GRAPH") != nullptr;
-    if (no_graph || (g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_prefill_eager(g, P, last_block_full, s);
-    if (g->graph_stream != s && !g->pf_graphs.empty()) {  // captured for another stream: start over
-        for (auto& e : g->pf_graphs)
-            if (e.exec) (void)hipGraphExecDestroy(e.exec);
-        g->pf_graphs.clear();
-    }
-    for (auto& e : g->pf_graphs)
-        if (e.P == P && e.full == last_block_full) {
-            if (e.seen_only) {  // second pass of this length: capture it
-                hipGraph_t graph = nullptr;
-                ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int st = enqueue_prefill_eager(g, P, last_block_full, s);
-                const hipError_t ce = hipStreamEndCapture(s, &graph);
-                if (st != ZG_OK || ce != hipSuccess) {
-                    if (graph) (void)hipGraphDestroy(graph);
-                    if (st != ZG_OK) return st;
-                    ZG_HIP(ce);
-                }
-                ZG_HIP(hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0));
-                ZG_HIP(hipGraphDestroy(graph));
-                e.seen_only = false;
-            }
-            ZG_HIP(hipGraphLaunch(e.exec, s));
-            return ZG_OK;
-        }
-    if (g->pf_graphs.size() < kMaxPrefillGraphs) g->pf_graphs.push_back(zg_gpt::PfGraph{P, last_block_full, true, nullptr});
-    return enqueue_prefill_eager(g, P, last_block_full, s);
-}
-
-int enqueue_prefill_eager(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
     if (g->wt == WT_F32) return enqueue_prefill_f32(g, P, last_block_full, s);
     const int np = (g->flags & ZG_GPT_PREFILL_2PLANE) ? 2 : kSplit;
     const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
@@ -1161,8 +1120,6 @@ int zg_gpt_destroy(zg_gpt* g) {
     if (g->s3) (void)hipStreamSynchronize(g->s3);
     drop_prefetcher(g);
     drop_graphs(g);
-    for (auto& e : g->pf_graphs)
-        if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
