@@ -999,7 +999,10 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
     g->spin_limit = (unsigned)env_int("ZGPT2_TAG_SPIN_LIMIT", 1 << 20);
     // Two-stream decode: one sequence, bf16 weights, graphs, at least two Blocks, and every kernel on the x edges one that
-    // knows granules (K-split kernels: n_embed <= 1024 for the head-merging c_proj, 4 n_embed >= 2048 for mlp c_proj)
+    // knows granules (K-split kernels: n_embed <= 1024 for the head-merging c_proj, 4 n_embed >= 2048 for mlp c_proj).
+    // n_embed <= 1024 is also the OCCUPANCY bound: a consumer is launched before its producer and polls from every workgroup
+    // it has, so consumer + producer must fit the chip together — at GPT-2 XL ln_1 + c_attn alone is 600 workgroups of the
+    // ~1024 that fit, and the producers queue behind the pollers until these give up (measured: every step timed out).
     g->dual_on = false;
     g->s2 = g->s3 = nullptr;
     g->ev_fork = g->ev_join = g->ev_join3 = nullptr;
