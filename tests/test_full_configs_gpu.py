@@ -104,13 +104,7 @@ def test_124m_eight_prompts_fp16_kv_cache(zg, monkeypatch):
     agree = float((ids16 == ids32).mean())
     assert agree > 0.5, agree  # a greedy run may leave the fp32 run's path at a near-tie and never return: ids are checked teacher-forced above
     m32.close()
-    monkeypatch.setenv("ZGPT2_NO_KV_H8", "1")
-    m8 = zgpt.GPT(cfg, batch=8, kv_f16=True)
-    m8.load_weights(w)
-    ids8 = m8.generate(prompts, 256)
-    m8.close()
     m16.close()
-    assert float((ids8 == ids16[:, :256]).mean()) > 0.9  # (the two load shapes sum in another order: identical ids are the rule, not the contract)
 
 
 def test_xl_full_size(zg):

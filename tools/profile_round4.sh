@@ -1,0 +1,52 @@
+#!/bin/bash
+# Usage (GPU box): tools/profile_round4.sh round4   -> gpurun_out/profiles_round4/* (copy what is judged into profiles/)
+# Round 4: kernel trace + FETCH / WRITE passes of the one-prompt 124M step (traffic.json), the bench lines (default with its
+# other_configs block, 8 prompts, 8 prompts with the fp16 cache, fp32 weights), the GEMM point (write-through stores): trace +
+# counter passes, gemm_bench with stamps, prefill timings.
+tag=$1
+out=gpurun_out/profiles_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PYTHONPATH=$GRAFT_REPO_ROOT
+trace() {
+  local name=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --stats -d $out/tr_$name -o t -- "$@" > $out/${name}_under_rocprof.json 2> $out/${name}_under_rocprof.err
+  python tools/rocpd_stats.py $(find $out/tr_$name -name "*.db" | head -1) $out/${tag}_${name}_kernel_stats.md > /dev/null
+  rm -rf $out/tr_$name
+}
+pmc() {
+  local name=$1 c=$2; shift 2
+  for attempt in 1 2 3; do
+    timeout 900 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_${name}_$c -o pmc -- "$@" > $out/pmc_${name}_$c.log 2> $out/pmc_${name}_$c.err
+    python tools/rocpd_pmc.py $(find $out/pmc_${name}_$c -name "*.db" | head -1) $out/${tag}_${name}_pmc_$c.md.new > /dev/null 2> $out/pmc_${name}_${c}_parse.err
+    rm -rf $out/pmc_${name}_$c
+    if [ -s $out/${tag}_${name}_pmc_$c.md.new ]; then mv $out/${tag}_${name}_pmc_$c.md.new $out/${tag}_${name}_pmc_$c.md; break; fi
+  done
+}
+python bench.py --steps 5 --warmup 1 > $out/${tag}_bench.json 2> $out/bench.err
+python bench.py --steps 3 --warmup 1 --prompts-per-gpu 8 --no-cpu-baseline > $out/${tag}_bench_8prompts.json 2> $out/bench_8prompts.err
+python bench.py --steps 3 --warmup 1 --prompts-per-gpu 8 --kv-f16 --no-cpu-baseline > $out/${tag}_bench_8prompts_kvf16.json 2> $out/bench_8prompts_kvf16.err
+python bench.py --steps 3 --warmup 1 --weights-f32 --no-cpu-baseline > $out/${tag}_bench_weights_f32.json 2> $out/bench_weights_f32.err
+ZGPT2_DUAL=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_dual.json 2> $out/bench_dual.err
+trace 124m python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs
+for c in FETCH_SIZE WRITE_SIZE; do
+  pmc 124m $c python3 tools/pmc_decode.py 124M 1
+  pmc 124m_8prompts $c python3 tools/pmc_decode.py 124M 8
+  pmc xl $c python3 tools/pmc_decode.py xl 1
+done
+for n in 124m_8prompts xl; do cp profiles/round3_${n}_kernel_stats.md $out/${tag}_${n}_kernel_stats.md 2>/dev/null; done
+python tools/make_traffic_json.py $out $tag > /dev/null 2> $out/traffic.err
+ZGPT2_GEMM_KERNEL=s4 trace gemm_s4 python3 tools/bench_gemm.py 8192
+: > $out/${tag}_gemm_s4_pmc.md
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-40)
+  ZGPT2_GEMM_KERNEL=s4 rocprofv3 --kernel-trace --pmc $c -d $out/pg_$n -o pmc -- python3 tools/bench_gemm.py 8192 > /dev/null 2> $out/pg_s4_$n.err
+  python tools/rocpd_pmc.py $(find $out/pg_$n -name "*.db" | head -1) 2>/dev/null | grep -i "gemm_\|^| kernel\|^|---" >> $out/${tag}_gemm_s4_pmc.md
+  rm -rf $out/pg_$n
+done
+{ ZGPT2_GEMM_DBG=256 tools/bin/gemm_bench -k s4 -stamps; tools/bin/gemm_bench -k p8 -nocheck; ZGPT2_GEMM_DBG=256 tools/bin/gemm_bench 16384 3072 768 -k s4 -stamps -nocheck; } > $out/${tag}_gemm_bench.txt 2>&1
+python tools/bench_prefill.py > $out/${tag}_prefill.jsonl 2> $out/prefill.err
+python tools/bench_prefill.py --batch 8 --lengths 128,1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
+python tools/bench_prefill.py --planes 2 --lengths 128,1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
+python tools/bench_prefill.py --weights-f32 --lengths 128,1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
+ls -la $out

@@ -214,7 +214,8 @@ void carve(zg_gpt* g, char* base) {
         g->pf_a = (bf16_t*)P(B * C * kSplit * E * 2);
         g->pf_h = (bf16_t*)P(B * C * kSplit * 4 * E * 2);
         // bf16 weights: 64 MiB of split-K partial sums; fp32 weights: a full fp32 [rows][4 E] GEMM output
-        g->pf_ws_floats = g->wt == WT_BF16 ? (size_t)(16u << 20) : B * C * 4 * E;
+        // split-K partials of the prompt GEMMs; fp32 weights: three weight-plane passes of [B ctx, 4 E] at the least
+        g->pf_ws_floats = g->wt == WT_BF16 ? (size_t)(16u << 20) : std::max((size_t)(16u << 20), 3 * B * C * 4 * E);
         g->pf_ws = (float*)P(g->pf_ws_floats * 4);
     }
     g->arena_bytes = (cv.off + 255) & ~(size_t)255;
@@ -577,50 +578,15 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
 // exactly as P calls of GPT.forward would (main.zig:331-334) and leaves the residual stream of all rows in
 // pf_x.  With `last_block_full` false the last Block stops after its cache append: nothing downstream of
 // it is needed when generation re-feeds the last prompt token (main.zig:337).
-// fp32 weights (ZG_GPT_WEIGHTS_F32): the same pass with both GEMM operands as exact bf16 plane triples — the six
-// plane products above 2^-24 of the leading one on the persistent MFMA GEMM (launch_gemm_planes), i.e. fp32-sgemm
-// grade Linears for checkpoints that are not bf16-representable; epilogues run as separate small kernels.
-int enqueue_prefill_f32(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
-    const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
-    const int B = (int)g->batch, M = (int)(g->batch * P), iE = (int)E;
-    auto planes = [&](int K) {
-        GemmPlanes pl{};
-        pl.lda = pl.ldb = kSplit * K;
-        pl.kpp = K / 64;
-        pl.npairs = 6;  // (x, w): lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi — smallest products first
-        pl.pa_bits = 0x001012u;
-        pl.pb_bits = 0x010210u;
-        return pl;
-    };
-    ZG_REQUIRE(E % 64 == 0 && E >= 128, ZG_ERR_UNSUPPORTED, "prefill with fp32 weights needs n_embed a multiple of 64 (>= 128)");
-    ZG_TRY(launch_embed_prefill(g->prompt, (int)C, B, (int)P, g->wte, g->wpe, g->wt, iE, g->pf_x, s));
-    ZG_TRY(launch_ln_split(g->pf_x, M, iE, g->layers[0].ln_1_g, g->layers[0].ln_1_b, 1e-5f, g->pf_a, s));
-    for (size_t l = 0; l < L; ++l) {
-        const zg_layer& y = g->layers[l];
-        const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_f16, y.k_cache, y.v_cache};
-        ZG_TRY(launch_gemm_planes(g->pf_a, y.c_attn_p, y.c_attn_b, g->pf_qkv, M, 3 * iE, planes(iE), 3 * iE, false, false, s));
-        ZG_TRY(launch_qkv_scatter(g->pf_qkv, M, qa, s));  // cache append of ops.zig:152-157
-        if (l + 1 == L && !last_block_full) break;
-        ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
-        const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
-        ZG_TRY(launch_gemm_planes(g->pf_a, y.c_proj_p, y.c_proj_b, g->pf_ws, M, iE, planes(iE), iE, false, false, s));
-        ZG_TRY(launch_resid_ln(g->pf_ws, g->pf_x, M, iE, &ln2, s));
-        ZG_TRY(launch_gemm_planes(g->pf_a, y.c_fc_p, y.c_fc_b, g->pf_ws, M, 4 * iE, planes(iE), 4 * iE, true, false, s));
-        ZG_TRY(launch_split3(g->pf_ws, (size_t)M, 4 * iE, g->pf_h, s));
-        const bool more = l + 1 < L;
-        const PrefillLn ln1{more ? g->layers[l + 1].ln_1_g : nullptr, more ? g->layers[l + 1].ln_1_b : nullptr, 1e-5f, g->pf_a};
-        ZG_TRY(launch_gemm_planes(g->pf_h, y.mlp_proj_p, y.mlp_proj_b, g->pf_ws, M, iE, planes(4 * iE), iE, false, false, s));
-        ZG_TRY(launch_resid_ln(g->pf_ws, g->pf_x, M, iE, more ? &ln1 : nullptr, s));
-    }
-    return ZG_OK;
-}
-
+// fp32 weights (ZG_GPT_WEIGHTS_F32): the same pass; the weight operand is then the exact three-term bf16 split of the fp32
+// matrix (plane-major, made when the tensor is loaded) and every GEMM runs as three partial passes of the same kernel — the
+// six plane products above 2^-24 of the leading one, fp32-sgemm grade (prefill.hip launch_prefill_gemm_wp).
 // (Measured and dropped in round 4: replaying this pass from a hipGraph per prompt length.  0.844 against 0.749 ms at 64
 // tokens, 1.645 against 1.553 ms at 1023 — the ~10 us a launch costs here is the kernels' own latency at these sizes, not host
 // overhead, and a graph launch adds its own ~10 us; profiles/round4_prefill_graph.jsonl.)
 int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
-    if (g->wt == WT_F32) return enqueue_prefill_f32(g, P, last_block_full, s);
-    const int np = (g->flags & ZG_GPT_PREFILL_2PLANE) ? 2 : kSplit;
+    const bool f32w = g->wt == WT_F32;
+    const int np = f32w ? kWeightPlanes : (g->flags & ZG_GPT_PREFILL_2PLANE) ? 2 : kSplit;
     const size_t E = g->cfg.n_embed, L = g->cfg.n_layer, H = g->cfg.n_heads, C = g->cfg.context_size;
     const int B = (int)g->batch, M = (int)(g->batch * P), iE = (int)E;
     ZG_TRY(launch_embed_prefill(g->prompt, (int)C, B, (int)P, g->wte, g->wpe, g->wt, iE, g->pf_x, s));
@@ -630,18 +596,18 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         // pf_a holds split(ln_1(x)) here: from the line above or from the tail of the previous Block's last GEMM
         // c_attn with the cache append of ops.zig:152-157 in its epilogue
         const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_f16, y.k_cache, y.v_cache};
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
+        ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_attn_p : (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
                                    g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
         ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
         const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
+        ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_proj_p : (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
                                    g->pf_ws_floats, &ln2, s, nullptr, np));
-        ZG_TRY(launch_prefill_gemm(g->pf_a, (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, g->pf_ws,
+        ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_fc_p : (const bf16_t*)y.c_fc_w, y.c_fc_b, g->pf_h, M, 4 * iE, iE, 0, PF_GELU_SPLIT, g->pf_ws,
                                    g->pf_ws_floats, nullptr, s, nullptr, np));
         const bool more = l + 1 < L;
         const PrefillLn ln1{more ? g->layers[l + 1].ln_1_g : nullptr, more ? g->layers[l + 1].ln_1_b : nullptr, 1e-5f, g->pf_a};
-        ZG_TRY(launch_prefill_gemm(g->pf_h, (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws,
+        ZG_TRY(launch_prefill_gemm(g->pf_h, f32w ? y.mlp_proj_p : (const bf16_t*)y.mlp_proj_w, y.mlp_proj_b, g->pf_x, M, iE, 4 * iE, iE, PF_RESID, g->pf_ws,
                                    g->pf_ws_floats, more ? &ln1 : nullptr, s, nullptr, np));
     }
     return ZG_OK;
@@ -1164,7 +1130,9 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
     if (mat && g->wt == WT_F32 && y.c_attn_p) {  // exact bf16 planes of the fp32 matrix for the whole-prompt GEMMs
         bf16_t* pl = slot == ZG_C_ATTN_W ? y.c_attn_p : slot == ZG_C_PROJ_W ? y.c_proj_p : slot == ZG_C_FC_W ? y.c_fc_p : y.mlp_proj_p;
         const int K = (slot == ZG_MLP_PROJ_W) ? (int)(4 * E) : (int)E;
-        ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), n / (size_t)K, K, pl, ctx().stream));
+        // plane-major [3][out][in]: the matrix as ONE row of out * in elements
+        ZG_REQUIRE(n < ((size_t)1 << 31), ZG_ERR_SHAPE, "weight matrix of %zu elements", n);
+        ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), 1, (int)n, pl, ctx().stream));
         ZG_HIP(hipStreamSynchronize(ctx().stream));
     }
     return ZG_OK;

@@ -528,12 +528,12 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     const unsigned sb = (unsigned)a.stride_b, sh = (unsigned)a.stride_h, st = (unsigned)a.stride_t | (a.ctrl ? 0x80000000u : 0u);
     const int* cw = a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(ctx().d_zero);
     const unsigned* ew = a.epoch ? a.epoch : reinterpret_cast<const unsigned*>(ctx().d_zero);
-    static const bool h8_off = getenv("ZGPT2_NO_KV_H8") != nullptr;  // A/B: the fp16 cache on the fp32 lane map (8-byte loads)
-    note_kernel((a.kv_f16 && a.stride_t == 64 && !h8_off) ? "attn_decode_h8_kernel" : (a.kv_f16 ? "attn_decode_kernel<_Float16>" : "attn_decode_kernel<float>"));
-    if (a.kv_f16 && a.stride_t == 64 && !h8_off)
+    // (fp16 cache: the model tier's head-major layout only — 128-byte rows, 8 lanes x 16 B; the first fp16 path, which kept the
+    // fp32 lane map and its 8-byte loads, lost to the fp32 cache and is gone)
+    ZG_REQUIRE(!a.kv_f16 || a.stride_t == 64, ZG_ERR_UNSUPPORTED, "attention: the fp16 cache needs contiguous 64-element rows");
+    note_kernel(a.kv_f16 ? "attn_decode_h8_kernel" : "attn_decode_kernel<float>");
+    if (a.kv_f16)
         hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
-    else if (a.kv_f16)
-        hipLaunchKernelGGL((attn_decode_kernel<_Float16>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     else
         hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     ZG_HIP(hipGetLastError());

@@ -160,11 +160,12 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 // A: [M][3K] bf16 (hi | mid | lo), B: [N][K] bf16, bias [N].  C: fp32 [M][ldc] (PF_F32, PF_RESID) or bf16
 // [M][3N] split planes (PF_GELU_SPLIT).  N % 64 == 0, K % 64 == 0, any M.
-template <int EPI, int NS, int NSPL = kSplit>  // NS 64-column strips per wave: the tile is 128 x (128 NS); NSPL activation planes multiplied
-__global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                              const float* __restrict__ bias, void* __restrict__ C, int M,
-                                                              int N, int K, int ldc, unsigned tp, int n_tiles,
-                                                              const PrefillQkv qa) {
+// (the body is shared by prefill_gemm_kernel and prefill_gemm_wp_kernel: sp = K slice of this workgroup, slab = the partial
+// slab it writes under PF_PARTIAL)
+template <int EPI, int NS, int NSPL>  // NS 64-column strips per wave: the tile is 128 x (128 NS); NSPL activation planes multiplied
+__device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+                                                  void* __restrict__ C, int M, int N, int K, int ldc, unsigned tp, int n_tiles,
+                                                  const PrefillQkv& qa, const int sp, const int slab) {
     // tp = tiles_n | split-K slices << 12 | activation planes << 24: the 14 preloaded argument dwords carry everything the
     // first DMA depends on (zg_common.h ZG_PIN; gridDim is a scalar load from the kernarg segment)
     const int tiles_n = (int)(tp & 0xfffu);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
-    const int sp = blockIdx.y, n_sp = (int)((tp >> 12) & 0xfffu);  // split-K slice (PF_PARTIAL only; otherwise 0 of 1)
+    const int n_sp = (int)((tp >> 12) & 0xfffu);  // split-K slices (PF_PARTIAL only; otherwise 1)
     const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
             if (EPI == PF_GELU_SPLIT) {
                 store_split4(reinterpret_cast<bf16_t*>(C) + (size_t)gm * kSplit * N + nw + cc * 4, N, v);
             } else if (EPI == PF_PARTIAL) {  // C is the workspace [n_sp][M][N]
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ((size_t)sp * M + gm) * N + nw + cc * 4) = v;
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ((size_t)slab * M + gm) * N + nw + cc * 4) = v;
             } else {
                 float* dst = reinterpret_cast<float*>(C) + (size_t)gm * ldc + nw + cc * 4;
                 if (EPI == PF_RESID) v += *reinterpret_cast<const f32x4*>(dst);
@@ -320,6 +321,32 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __re
             }
         }
     }
+}
+
+template <int EPI, int NS, int NSPL = kSplit>
+__global__ __launch_bounds__(256, 1) void prefill_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                              const float* __restrict__ bias, void* __restrict__ C, int M,
+                                                              int N, int K, int ldc, unsigned tp, int n_tiles,
+                                                              const PrefillQkv qa) {
+    prefill_gemm_body<EPI, NS, NSPL>(A, B, bias, C, M, N, K, ldc, tp, n_tiles, qa, (int)blockIdx.y, (int)blockIdx.y);
+}
+
+// fp32 WEIGHTS: B is the exact three-term bf16 split of the fp32 matrix, plane-major [3][N][K] (hi, mid, lo).  The six plane
+// products above 2^-24 of the leading one are three passes over the K slices — w_lo x a_hi, w_mid x (a_mid + a_hi),
+// w_hi x (a_lo + a_mid + a_hi): one weight plane each with 1 / 2 / 3 activation planes — dealt over blockIdx.y = pass * n_sp +
+// slice and written as partial slabs in that order (smallest terms first), which the reduce kernels sum and finish.  One
+// launch per Linear; 128-row tiles and K slices fill the chip at any prompt length.
+template <int NS>
+__global__ __launch_bounds__(256, 1) void prefill_gemm_wp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                 const float* __restrict__ bias, void* __restrict__ C, int M, int N,
+                                                                 int K, int ldc, unsigned tp, int n_tiles, const PrefillQkv qa) {
+    const int n_sp = (int)((tp >> 12) & 0xfffu), y = (int)blockIdx.y;
+    // dispatched heaviest first (w_hi with three activation planes), slabs ordered smallest terms first
+    const int sched = y / n_sp, sp = y - sched * n_sp, slab = (2 - sched) * n_sp + sp;
+    const size_t plane = (size_t)N * K;
+    if (sched == 0) prefill_gemm_body<PF_PARTIAL, NS, 3>(A, B, bias, C, M, N, K, ldc, tp, n_tiles, qa, sp, slab);
+    else if (sched == 1) prefill_gemm_body<PF_PARTIAL, NS, 2>(A, B + plane, bias, C, M, N, K, ldc, tp, n_tiles, qa, sp, slab);
+    else prefill_gemm_body<PF_PARTIAL, NS, 1>(A, B + 2 * plane, bias, C, M, N, K, ldc, tp, n_tiles, qa, sp, slab);
 }
 
 // Second half of a split-K GEMM: sum the slices in fixed order (deterministic), add bias, apply the epilogue.
@@ -447,9 +474,41 @@ int launch_prefill_gemm_np(const bf16_t* A, const bf16_t* B, const float* bias, 
     return ZG_OK;
 }
 
+// fp32 weights (nsplit = kWeightPlanes): prefill_gemm_wp_kernel + the reduce kernels (which apply the epilogue)
+template <int EPI, int NS>
+int launch_prefill_gemm_wp(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, float* ws,
+                           size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, hipStream_t s) {
+    static bool raised = false;
+    if (!raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_gemm_wp_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(NS)));
+        raised = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN * NS - 1) / (BN * NS), tiles = tiles_m * tiles_n;
+    const int nt = K / BK;
+    int n_sp = (256 + 3 * tiles - 1) / (3 * tiles);  // three passes per slice: about one workgroup per CU in all
+    if (n_sp > nt / 3) n_sp = nt / 3;
+    if (n_sp < 1) n_sp = 1;
+    while (n_sp > 1 && (size_t)3 * n_sp * M * N > ws_floats) --n_sp;
+    ZG_REQUIRE(ws && (size_t)3 * n_sp * M * N <= ws_floats, ZG_ERR_ARG, "prefill GEMM (fp32 weights): workspace of %zu floats for %d x %d", ws_floats, M, N);
+    hipLaunchKernelGGL((prefill_gemm_wp_kernel<NS>), dim3(tiles, 3 * n_sp), dim3(256), lds_bytes(NS), s, A, B, bias, (void*)ws, M, N, K, ldc,
+                       (unsigned)tiles_n | ((unsigned)n_sp << 12), tiles, qa);
+    if (EPI == PF_RESID && ln && ldc == N && N <= 2048) {
+        hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, 3 * n_sp, bias, reinterpret_cast<float*>(C), M, N, ln->g,
+                           ln->b, ln->eps, ln->out);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    const size_t n = (size_t)M * (N / 4);
+    hipLaunchKernelGGL((prefill_reduce_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, 3 * n_sp, bias, C, M, N, ldc, qa);
+    ZG_HIP(hipGetLastError());
+    if (EPI == PF_RESID && ln) return launch_ln_split(reinterpret_cast<const float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out, s);
+    return ZG_OK;
+}
+
 template <int EPI, int NS>
 int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
                            float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, int nsplit, hipStream_t s) {
+    if (nsplit == kWeightPlanes) return launch_prefill_gemm_wp<EPI, NS>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
     if (nsplit == 2) return launch_prefill_gemm_np<EPI, NS, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
     return launch_prefill_gemm_np<EPI, NS, kSplit>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, s);
 }
@@ -667,44 +726,10 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
     return ZG_OK;
 }
 
-// Cache append of ops.zig:152-157 for qkv rows that a plain GEMM produced: K / V columns -> head-major caches.
-__global__ __launch_bounds__(256) void qkv_scatter_kernel(const float* __restrict__ qkv, int M, const PrefillQkv qa) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int n4 = (2 * qa.E) / 4;
-    if (i >= (size_t)M * n4) return;
-    const int m = (int)(i / n4), n = qa.E + (int)(i % n4) * 4;
-    qkv_cache_store(qa, m, n, *reinterpret_cast<const f32x4*>(qkv + (size_t)m * 3 * qa.E + n));
-}
-
-int launch_qkv_scatter(const float* qkv, int M, const PrefillQkv& qa, hipStream_t s) {
-    const size_t n = (size_t)M * (2 * qa.E / 4);
-    hipLaunchKernelGGL(qkv_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, M, qa);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
-}
-
-// x += t (t = a finished GEMM output incl. bias), then (optionally) the LayerNorm of the updated rows as split planes
-// (main.zig:136-145 residual adds + the LayerNorm that follows): the split-K tail kernels with a single slice.
-int launch_resid_ln(const float* t, float* x, int M, int N, const PrefillLn* ln, hipStream_t s) {
-    if (ln && ln->g && N <= 2048) {
-        hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, t, 1, (const float*)nullptr, x, M, N, ln->g,
-                           ln->b, ln->eps, ln->out);
-        ZG_HIP(hipGetLastError());
-        return ZG_OK;
-    }
-    const size_t n = (size_t)M * (N / 4);
-    const PrefillQkv none{};
-    hipLaunchKernelGGL((prefill_reduce_kernel<PF_RESID>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, 1,
-                       (const float*)nullptr, (void*)x, M, N, N, none);
-    ZG_HIP(hipGetLastError());
-    if (ln && ln->g) return launch_ln_split(x, M, N, ln->g, ln->b, ln->eps, ln->out, s);
-    return ZG_OK;
-}
-
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
                         float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv, int nsplit) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
-    ZG_REQUIRE(nsplit == 2 || nsplit == kSplit, ZG_ERR_ARG, "prefill gemm: %d activation planes", nsplit);
+    ZG_REQUIRE(nsplit == 2 || nsplit == kSplit || nsplit == kWeightPlanes, ZG_ERR_ARG, "prefill gemm: %d activation planes", nsplit);
     const PrefillQkv none{};
     switch (epi) {
         case PF_F32: return launch_prefill_gemm_t<PF_F32>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, none, nsplit, s);

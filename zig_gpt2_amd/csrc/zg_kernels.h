@@ -228,10 +228,9 @@ struct PrefillLn {
 };
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
                         float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv = nullptr,
-                        int nsplit = kSplit);  // nsplit = 2: multiply the hi + mid planes only (2/3 of the matrix work)
-// fp32-weight prefill helpers: KV cache append from finished qkv rows; residual add (+ LayerNorm -> planes)
-int launch_qkv_scatter(const float* qkv, int M, const PrefillQkv& qa, hipStream_t s);
-int launch_resid_ln(const float* t, float* x, int M, int N, const PrefillLn* ln, hipStream_t s);
+                        int nsplit = kSplit);  // nsplit = 2: multiply the hi + mid planes only (2/3 of the matrix work);
+                                               // kWeightPlanes: W is the plane-major three-term split [3][N][K] of an fp32 matrix
+constexpr int kWeightPlanes = 33;
 // out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t)
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s);
 
