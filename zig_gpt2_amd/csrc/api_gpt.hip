@@ -25,7 +25,7 @@ struct zg_layer {
     // ZG_GPT_WEIGHTS_F32 handles only: the same matrices split exactly into bf16 planes [out][3 in] = [hi | mid | lo]
     // (filled when the tensor is loaded) — the B operand of the whole-prompt GEMMs
     bf16_t *c_attn_p, *c_proj_p, *c_fc_p, *mlp_proj_p;
-    // LayerNorm folded out of the two LayerNorm-fed Linears (gemv.hip, gemv_lnk_kernel): c2 = W g, c3 = W b + bias
+    // LayerNorm folded out of the two LayerNorm-fed Linears (gemv_ksplit.hip, gemv_lnk_kernel): c2 = W g, c3 = W b + bias
     float *c_attn_c2, *c_attn_c3, *c_fc_c2, *c_fc_c3;
     float *ln_1_g, *ln_1_b, *c_attn_b, *c_proj_b, *ln_2_g, *ln_2_b, *c_fc_b, *mlp_proj_b;
     void *k_cache, *v_cache;
@@ -1129,7 +1129,6 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
     ZG_TRY(upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream));
     if (mat && g->wt == WT_F32 && y.c_attn_p) {  // exact bf16 planes of the fp32 matrix for the whole-prompt GEMMs
         bf16_t* pl = slot == ZG_C_ATTN_W ? y.c_attn_p : slot == ZG_C_PROJ_W ? y.c_proj_p : slot == ZG_C_FC_W ? y.c_fc_p : y.mlp_proj_p;
-        const int K = (slot == ZG_MLP_PROJ_W) ? (int)(4 * E) : (int)E;
         // plane-major [3][out][in]: the matrix as ONE row of out * in elements
         ZG_REQUIRE(n < ((size_t)1 << 31), ZG_ERR_SHAPE, "weight matrix of %zu elements", n);
         ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), 1, (int)n, pl, ctx().stream));

@@ -92,10 +92,10 @@ __device__ __forceinline__ float row16_reduce_scatter(float (&s)[16], int lr) {
 
 // Wave 0 of a split hands over its partial (o[lane], M, l).  Op tier / one sequence: plain stores, the consumer merges
 // (attn_merge_kernel, or the c_proj prologue).  Lock-step batch with activation planes (AttnArgs.pl_out): the LAST split
-// of (b, h) to arrive merges all of them — same arithmetic as merge_attn4 in gemv.hip: weights exp(m_s - max m), sums
+// of (b, h) to arrive merges all of them — same arithmetic as merge_attn4 in gemv_internal.h: weights exp(m_s - max m), sums
 // in split order, one reciprocal — and writes the head's 64 outputs as the three bf16 planes the c_proj Linear loads as
 // MFMA A fragments (zg_common.h plane_elem).  Publish with write-through (agent-scope relaxed atomic) stores, drain
-// them, take a ticket, read back with agent-scope loads: the fence-free pattern of the split-K Linears (gemv.hip).
+// them, take a ticket, read back with agent-scope loads: the fence-free pattern of the split-K Linears (gemv_mfma16.hip).
 __device__ __forceinline__ void publish_partial(const AttnArgs& a, int n_heads, int nsplit, int b, int h, int split, int lane, float o,
                                                 float M, float l, unsigned tag) {
     float* part = a.part + (((size_t)b * n_heads + h) * a.max_splits + split) * kPartStride;
