@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--prompts-per-gpu", type=int, default=0, help="0 = 1 prompt at N=1, 8 per GPU at N>1")
     p.add_argument("--ctx", type=int, default=0, help="decode steps per generation (default: context_size)")
     p.add_argument("--kv-f16", action="store_true")
+    p.add_argument("--kv-b24", action="store_true", help="24-bit KV cache (bf16 plane + byte plane), ZG_GPT_KV_B24")
     p.add_argument("--weights-f32", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-prefetch", action="store_true", help="no side-stream L2 prefetcher beside the decode chain (A/B)")
@@ -232,7 +233,7 @@ def device_weights(cfg, seed):
     return w
 
 
-def other_config(lib, stream, model_name, ppg, gens, seed):
+def other_config(lib, stream, model_name, ppg, gens, seed, kv_b24=False):
     """One of BASELINE.json's other single-GPU workloads, driver-timed in the same run: tokens/s of `gens` full greedy
     generations (after one warm-up generation), device time per forward, whole-step roofline fraction, dominant kernel class."""
     import torch
@@ -241,7 +242,8 @@ def other_config(lib, stream, model_name, ppg, gens, seed):
 
     cfg = synth.CONFIGS[model_name]
     ctx = cfg.context_size
-    model = gpt.GPT(cfg, batch=ppg)
+    model = gpt.GPT(cfg, batch=ppg, kv_b24=kv_b24)
+    kvb = 3 if kv_b24 else 4
     try:
         w = device_weights(cfg, seed)
         model.load_weights(w)
@@ -261,14 +263,15 @@ def other_config(lib, stream, model_name, ppg, gens, seed):
         ids = model.generate_fetch(ctx)
         pf = model.prefetch_stats()
         wbytes, _ = model.step_bytes(1)
-        kv_total = sum(4 * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
+        kv_total = sum(kvb * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
         step_bytes_total = wbytes * ctx + kv_total
-        table, dom, lm = kernel_table(model, lib, cfg, ppg, 2, 4)
+        table, dom, lm = kernel_table(model, lib, cfg, ppg, 2, kvb)
         return {
             "workload": f"GPT-2 {model_name} greedy decode, {ppg} prompt(s) on one GPU, 1-token prompts, {ctx} decode steps per prompt",
             "value": round(ppg * (ctx - 1) * gens / wall, 1), "unit": "tokens/s", "generations": gens, "ms_per_generation": round(1e3 * wall / gens, 3),
             "us_per_forward_device": round(1e6 * dev_s / (gens * ctx), 2),
-            "kv_cache": "f32", "l2_prefetcher": ("stalled" if pf["stalled"] else "on") if pf["on"] else "off",
+            "kv_cache": "b24 (ZG_GPT_KV_B24: 24-bit elements, 4.7e-5 of the logit scale at full context)" if kv_b24 else "f32",
+            "l2_prefetcher": ("stalled" if pf["stalled"] else "on") if pf["on"] else "off",
             "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_generation": int(step_bytes_total),
                               "achieved": round(step_bytes_total * gens / dev_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(step_bytes_total * gens / dev_s / 1e9 / HBM_PEAK_GBS, 4)},
@@ -317,7 +320,7 @@ def main():
     cfg = synth.CONFIGS[a.model]
     ctx = a.ctx or cfg.context_size
     ppg = a.prompts_per_gpu or (1 if world == 1 else 8)
-    model = gpt.GPT(cfg, batch=ppg, weights_f32=a.weights_f32, use_graph=not a.no_graph, kv_f16=a.kv_f16, prefetch=not a.no_prefetch)
+    model = gpt.GPT(cfg, batch=ppg, weights_f32=a.weights_f32, use_graph=not a.no_graph, kv_f16=a.kv_f16, kv_b24=a.kv_b24, prefetch=not a.no_prefetch)
 
     # ---- weights: generated and uploaded on rank 0, broadcast to the other GPUs over RCCL/xGMI
     weights = None
@@ -386,7 +389,7 @@ def main():
     # are reported beside it.
     wbytes, _ = model.step_bytes(1)
     wsz = 4 if a.weights_f32 else 2
-    kv_elem = 2 if a.kv_f16 else 4
+    kv_elem = 2 if a.kv_f16 else 3 if a.kv_b24 else 4
     table, dom, lm = kernel_table(model, lib, cfg, ppg, wsz, kv_elem)
     n_prof = min(64, ctx)
     prof_lo = model.profile_step(1, n_prof)
@@ -442,7 +445,7 @@ def main():
                                  "persistent MFMA GEMM" if a.weights_f32 else
                                  "activations split exactly 3-way into bf16 for the MFMA GEMMs") + ", fp32-MFMA causal attention"}
             if not a.weights_f32:  # the two-plane mode (inside north_star's 1e-3, outside the tests' near-zero floor)
-                m2 = gpt.GPT(cfg, batch=ppg, use_graph=False, kv_f16=a.kv_f16, prefill_planes=2)
+                m2 = gpt.GPT(cfg, batch=ppg, use_graph=False, kv_f16=a.kv_f16, kv_b24=a.kv_b24, prefill_planes=2)
                 m2.load_weights(weights)
                 p2_ms = time_prefill(m2)
                 m2.close()
@@ -452,12 +455,12 @@ def main():
             prefill = {"error": str(e)}
     # BASELINE.json configs[2..4] on this GPU, one handle after another (the headline handle stays: its numbers are above)
     others = None
-    if a.model == "124M" and world == 1 and ppg == 1 and not a.weights_f32 and not a.kv_f16 and not a.no_other_configs:
+    if a.model == "124M" and world == 1 and ppg == 1 and not a.weights_f32 and not a.kv_f16 and not a.kv_b24 and not a.no_other_configs:
         others = []
-        for mname, mp, gens in (("124M", 8, 2), ("xl", 1, 1), ("nano-char", 1, 3)):
+        for mname, mp, gens, b24 in (("124M", 8, 2, False), ("124M", 8, 2, True), ("xl", 1, 1, False), ("nano-char", 1, 3, False)):
             try:
                 t_o = time.perf_counter()
-                o = other_config(lib, stream, mname, mp, gens, a.seed + 7)
+                o = other_config(lib, stream, mname, mp, gens, a.seed + 7, kv_b24=b24)
                 o["seconds_spent"] = round(time.perf_counter() - t_o, 1)
                 others.append(o)
             except Exception as e:
@@ -484,7 +487,7 @@ def main():
                         f"{ctx} decode steps per prompt (reference generate loop, src/main.zig:322-342)",
             "vocab": cfg.vocab_size, "context": cfg.context_size, "n_layer": cfg.n_layer, "n_heads": cfg.n_heads,
             "n_embed": cfg.n_embed, "prompts_per_gpu": ppg, "global_prompts": ppg * world,
-            "kv_cache": "f16" if a.kv_f16 else "f32", "hip_graph": not a.no_graph,
+            "kv_cache": "f16" if a.kv_f16 else "b24" if a.kv_b24 else "f32", "hip_graph": not a.no_graph,
             "l2_prefetcher": ("stalled" if pf["stalled"] else "on") if pf["on"] else "off",
             "parallelism": f"replicated weights, prompts sharded x{world}, RCCL broadcast at start-up only",
             "tokens_counted": "generated tokens (context - prompt) per prompt",

@@ -163,8 +163,12 @@ enum {
     ZG_GPT_PREFILL_2PLANE = 1 << 4, /* whole-prompt GEMMs multiply two bf16 planes of the fp32 activations instead of the exact
                                       three: 2/3 of the matrix work, ~2e-5 of the logit scale (inside the 1e-3 parity bound,
                                       outside the tests' near-zero floor); bf16-weight handles only */
-    ZG_GPT_NO_PREFETCH = 1 << 5  /* zg_gpt_generate_*: no side-stream L2 prefetcher beside the decode chain (results are
+    ZG_GPT_NO_PREFETCH = 1 << 5, /* zg_gpt_generate_*: no side-stream L2 prefetcher beside the decode chain (results are
                                     identical either way; a measurement switch) */
+    ZG_GPT_KV_B24 = 1 << 6       /* store the KV cache as 24-bit floats (the fp32 value rounded to 16 mantissa bits, kept as a
+                                    bf16 plane + a plane of 8 more mantissa bits): 3/4 of the fp32 cache's traffic, 2^-17 per
+                                    cached element — inside the 1e-3 parity bound at full context, unlike ZG_GPT_KV_F16 (which
+                                    it excludes) */
 };
 
 /* Per-block tensor slots (load_block, src/main.zig:271-302) and top-level slots (load_gpt,

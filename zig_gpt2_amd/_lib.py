@@ -82,6 +82,7 @@ SIGNATURES = {
 
 # flags / slots of include/zgpt2.h
 GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL, GPT_PREFILL_2PLANE, GPT_NO_PREFETCH = 0, 1, 2, 4, 8, 16, 32
+GPT_KV_B24 = 64
 BLOCK_SLOTS = ["ln_1_g", "ln_1_b", "c_attn_w", "c_attn_b", "c_proj_w", "c_proj_b",
                "ln_2_g", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b"]
 TOP_SLOTS = ["wte", "wpe", "ln_f_g", "ln_f_b"]

@@ -36,7 +36,7 @@ struct zg_gpt {
     size_t batch;
     unsigned flags;
     int wt;        // WT_BF16 / WT_F32
-    int kv_f16;
+    int kv_mode;
     size_t wbytes;  // bytes per matrix element
     char* arena;
     size_t arena_bytes, weight_region_bytes;
@@ -129,7 +129,7 @@ struct Carver {
 void carve(zg_gpt* g, char* base) {
     const zg_gpt_config& c = g->cfg;
     const size_t E = c.n_embed, V = c.vocab_size, C = c.context_size, L = c.n_layer, B = g->batch;
-    const size_t wb = g->wbytes, kvb = g->kv_f16 ? 2 : 4;
+    const size_t wb = g->wbytes, kvb = g->kv_mode == 1 ? 2 : g->kv_mode == 2 ? 3 : 4;  // B24: a bf16 plane, then a byte plane
     Carver cv;
     auto P = [&](size_t bytes) -> char* {
         const size_t o = cv.take(bytes);
@@ -242,7 +242,8 @@ GemvArgs base_gemv(const zg_gpt* g, const void* W, const float* bias, size_t N, 
     a.head_dim = 64;
     a.max_splits = g->max_splits;
     a.ctx = (int)g->cfg.context_size;
-    a.kv_f16 = g->kv_f16;
+    a.kv_mode = g->kv_mode;
+    a.kv_lo = g->batch * g->cfg.context_size * g->cfg.n_embed * 2;
     a.sk_ws = g->sk_ws;
     a.sk_cnt = g->sk_cnt;
     a.sk_tiles = g->sk_tiles;
@@ -437,7 +438,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.stride_b = (long)(g->cfg.context_size * E);
             a.stride_h = (long)(g->cfg.context_size * 64);
             a.stride_t = 64;
-            a.kv_f16 = g->kv_f16;
+            a.kv_mode = g->kv_mode;
+            a.kv_lo = g->batch * g->cfg.context_size * E * 2;
             a.n_heads = (int)g->cfg.n_heads;
             a.head_dim = 64;
             a.batch = (int)g->batch;
@@ -466,7 +468,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 j.n_heads = (unsigned)g->cfg.n_heads;
                 j.ctx = (unsigned)g->cfg.context_size;
                 j.batch = (unsigned)g->batch;
-                j.row_bytes = g->kv_f16 ? 128u : 256u;
+                j.row_bytes = g->kv_mode ? 128u : 256u;  // (B24: the bf16 plane; its byte plane is left to the kernel)
                 rec->push_back(j);
             } else
                 ZG_TRY(launch_attn_decode(a, s));
@@ -595,7 +597,7 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         const zg_layer& y = g->layers[l];
         // pf_a holds split(ln_1(x)) here: from the line above or from the tail of the previous Block's last GEMM
         // c_attn with the cache append of ops.zig:152-157 in its epilogue
-        const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_f16, y.k_cache, y.v_cache};
+        const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_mode, y.k_cache, y.v_cache, g->batch * C * E * 2};
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_attn_p : (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
                                    g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
@@ -907,13 +909,14 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     ZG_REQUIRE(c.n_embed % 8 == 0 && c.n_embed * 4 <= 8192, ZG_ERR_UNSUPPORTED, "n_embed %zu unsupported", c.n_embed);
     ZG_REQUIRE(batch >= 1 && batch <= 8, ZG_ERR_UNSUPPORTED, "batch %zu outside 1..8", batch);
     ZG_REQUIRE(c.vocab_size > 0 && c.context_size > 0 && c.n_layer > 0, ZG_ERR_ARG, "empty config");
+    ZG_REQUIRE(!(flags & ZG_GPT_KV_F16) || !(flags & ZG_GPT_KV_B24), ZG_ERR_ARG, "ZG_GPT_KV_F16 and ZG_GPT_KV_B24 exclude each other");
     zg_gpt* g = new zg_gpt();
     g->cfg = c;
     g->batch = batch;
     g->flags = flags;
     g->wt = (flags & ZG_GPT_WEIGHTS_F32) ? WT_F32 : WT_BF16;
     g->wbytes = g->wt == WT_BF16 ? 2 : 4;
-    g->kv_f16 = (flags & ZG_GPT_KV_F16) ? 1 : 0;
+    g->kv_mode = (flags & ZG_GPT_KV_F16) ? 1 : (flags & ZG_GPT_KV_B24) ? 2 : 0;
     g->max_splits = (int)((c.context_size + kAttnChunk - 1) / kAttnChunk);
     g->graph_stream = nullptr;
     carve(g, nullptr);
@@ -1178,7 +1181,7 @@ int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* k
     const size_t E = g->cfg.n_embed;
     // wbytes * (sum_layers in*out + V*E) + kvbytes * 2 * T * E * L (per sequence)
     if (weight_bytes) *weight_bytes = g->wbytes * (g->cfg.n_layer * 12 * E * E + g->cfg.vocab_size * E);
-    if (kv_bytes) *kv_bytes = (g->kv_f16 ? 2 : 4) * 2 * seq_len * E * g->cfg.n_layer * g->batch;
+    if (kv_bytes) *kv_bytes = (g->kv_mode == 1 ? 2 : g->kv_mode == 2 ? 3 : 4) * 2 * seq_len * E * g->cfg.n_layer * g->batch;
     return ZG_OK;
 }
 

@@ -400,6 +400,31 @@ __device__ __forceinline__ float grp8_reduce_scatter(float (&s)[8], int c) {
     return keep + (hi ? from_lo : from_hi);
 }
 
+// Eight cached elements of one lane, as loaded: fp16 (16 B), or B24 (16 B of the bf16 plane + 8 B of the byte plane; one
+// v_perm_b32 per element rebuilds the fp32 bit pattern {hi16, lo8, 0}, where the fp16 row costs one v_cvt_f32_f16).
+template <int MODE>
+struct Row8;
+template <>
+struct Row8<1> {
+    h8 v;
+    __device__ __forceinline__ void load(const void* base, size_t, size_t elem) { v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(base) + elem); }
+    __device__ __forceinline__ float at(int e) const { return (float)v[e]; }
+};
+template <>
+struct Row8<2> {
+    u32x4 hi;
+    u32x2 lo;
+    __device__ __forceinline__ void load(const void* base, size_t lo_off, size_t elem) {
+        hi = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+        lo = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(base) + lo_off + elem);
+    }
+    __device__ __forceinline__ float at(int e) const {  // (e is a constant after unrolling)
+        const uint32_t sel = ((e & 1) ? 0x07060000u : 0x05040000u) | ((uint32_t)(e & 3) << 8) | 0x0cu;
+        return __uint_as_float(__builtin_amdgcn_perm(hi[e >> 1], lo[e >> 2], sel));
+    }
+};
+
+template <int MODE>
 __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __restrict__ qp0, const void* __restrict__ kp,
                                                              const void* __restrict__ vp, unsigned sb, unsigned sh, unsigned st,
                                                              unsigned th, const int* __restrict__ cw, const unsigned* __restrict__ ew,
@@ -418,8 +443,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 7, g8 = lane >> 3;
     const int base = chunk0 + wave * 64;
-    const _Float16* K = reinterpret_cast<const _Float16*>(kp) + (size_t)b * sb + (size_t)h * sh;
-    const _Float16* V = reinterpret_cast<const _Float16*>(vp) + (size_t)b * sb + (size_t)h * sh;
+    const size_t head0 = (size_t)b * sb + (size_t)h * sh;  // element index of this head's first row
     const float* qp = qp0 + ((size_t)b * n_heads + h) * 64 + c * 8;
     const f32x4 qa = *reinterpret_cast<const f32x4*>(qp), qb = *reinterpret_cast<const f32x4*>(qp + 4);
     const float q[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
@@ -428,12 +452,12 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
     float m_w = kNegBig, l_w = 0.0f;
     float o[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (base < t_hi) {
-        h8 k8[8], v8[8];
+        Row8<MODE> k8[8], v8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {  // branch-free, as above
             const int t = min(base + 8 * i + g8, t_hi - 1);
-            k8[i] = *reinterpret_cast<const h8*>(K + (size_t)t * stride_t + c * 8);
-            v8[i] = *reinterpret_cast<const h8*>(V + (size_t)t * stride_t + c * 8);
+            k8[i].load(kp, a.kv_lo, head0 + (size_t)t * stride_t + c * 8);
+            v8[i].load(vp, a.kv_lo, head0 + (size_t)t * stride_t + c * 8);
         }
         ZG_PIN(a.progress); ZG_PIN(a.part); ZG_PIN(a.max_splits); ZG_PIN(a.pl_out); ZG_PIN(a.part_tag); ZG_PIN(a.launch_id); ZG_PIN(a.merge_cnt); ZG_PIN(a.fault); ZG_PIN(a.spin_limit);
         pf_count(a.progress);
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
         for (int i = 0; i < 8; ++i) {
             float acc = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf(q[e], (float)k8[i][e], acc);
+            for (int e = 0; e < 8; ++e) acc = fmaf(q[e], k8[i].at(e), acc);
             s[i] = acc;
         }
         float sc = grp8_reduce_scatter(s, c) * alpha;  // lane (g8, c): position base + 8 c + g8
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_decode_h8_kernel(const float* __rest
         const float plo = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x150 + (i), 0xF, 0xF, false));     \
         const float phi = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x150 + 8 + (i), 0xF, 0xF, false)); \
         const float pi = up ? phi : plo;                                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = fmaf(pi, (float)v8[i][e], o[e]);                              \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = fmaf(pi, v8[i].at(e), o[e]);                              \
     }
         ZG_PV8(0) ZG_PV8(1) ZG_PV8(2) ZG_PV8(3) ZG_PV8(4) ZG_PV8(5) ZG_PV8(6) ZG_PV8(7)
 #undef ZG_PV8
@@ -530,10 +554,13 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     const unsigned* ew = a.epoch ? a.epoch : reinterpret_cast<const unsigned*>(ctx().d_zero);
     // (fp16 cache: the model tier's head-major layout only — 128-byte rows, 8 lanes x 16 B; the first fp16 path, which kept the
     // fp32 lane map and its 8-byte loads, lost to the fp32 cache and is gone)
-    ZG_REQUIRE(!a.kv_f16 || a.stride_t == 64, ZG_ERR_UNSUPPORTED, "attention: the fp16 cache needs contiguous 64-element rows");
-    note_kernel(a.kv_f16 ? "attn_decode_h8_kernel" : "attn_decode_kernel<float>");
-    if (a.kv_f16)
-        hipLaunchKernelGGL(attn_decode_h8_kernel, grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
+    ZG_REQUIRE(!a.kv_mode || a.stride_t == 64, ZG_ERR_UNSUPPORTED, "attention: the 16- / 24-bit caches need contiguous 64-element rows");
+    ZG_REQUIRE(a.kv_mode >= 0 && a.kv_mode <= 2, ZG_ERR_ARG, "attention: cache mode %d", a.kv_mode);
+    note_kernel(a.kv_mode == 1 ? "attn_decode_h8_kernel<1>" : a.kv_mode == 2 ? "attn_decode_h8_kernel<2>" : "attn_decode_kernel<float>");
+    if (a.kv_mode == 1)
+        hipLaunchKernelGGL((attn_decode_h8_kernel<1>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
+    else if (a.kv_mode == 2)
+        hipLaunchKernelGGL((attn_decode_h8_kernel<2>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     else
         hipLaunchKernelGGL((attn_decode_kernel<float>), grid, dim3(256), 0, s, a.q, a.k, a.v, sb, sh, st, th, cw, ew, a);
     ZG_HIP(hipGetLastError());

@@ -162,7 +162,8 @@ __device__ __forceinline__ float epilogue_row(const GemvArgs& a, int m, int n, f
                 }
                 const size_t off = (((size_t)m * a.n_heads + h) * a.ctx + pos) * a.head_dim + d;
                 void* cache = which ? a.v_cache : a.k_cache;
-                if (a.kv_f16) kv_store<_Float16>(cache, off, v);
+                if (a.kv_mode == 1) kv_store<_Float16>(cache, off, v);
+                else if (a.kv_mode == 2) b24_store(cache, a.kv_lo, off, v);
                 else kv_store<float>(cache, off, v);
             }
             break;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gemv_pl4_kernel(const bf16_t* __restrict_
         ZG_PIN(a.progress); ZG_PIN(a.pl_out); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
         ZG_PIN(a.st_out);
         if (epilogue == EPI_QKV) {
-            ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_f16);
+            ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_mode); ZG_PIN(a.kv_lo);
         }
         if constexpr (KSL > 1) {
             ZG_PIN(a.sk_tag); ZG_PIN(a.launch_id); ZG_PIN(a.sk_ws); ZG_PIN(a.sk_cnt); ZG_PIN(a.fault); ZG_PIN(a.spin_limit);

@@ -113,7 +113,12 @@ __device__ __forceinline__ void qkv_cache_store(const PrefillQkv& q, int m, int 
     const int b = m / q.P, t = m - b * q.P;
     const size_t off = (((size_t)b * q.H + (e >> 6)) * q.ctx + t) * 64 + (e & 63);
     void* cache = which ? q.v_cache : q.k_cache;
-    if (q.kv_f16) {
+    if (q.kv_mode == 2) {  // four elements: 8 bytes of the bf16 plane, 4 of the byte plane
+        const uint32_t r0 = b24_round(v.x), r1 = b24_round(v.y), r2 = b24_round(v.z), r3 = b24_round(v.w);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(cache) + off) = u32x2{(r0 >> 8) | ((r1 >> 8) << 16), (r2 >> 8) | ((r3 >> 8) << 16)};
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cache) + q.kv_lo + off) =
+            (r0 & 0xffu) | ((r1 & 0xffu) << 8) | ((r2 & 0xffu) << 16) | (r3 << 24);
+    } else if (q.kv_mode) {
         _Float16* d = reinterpret_cast<_Float16*>(cache) + off;
         const float lim = 65504.0f;  // saturate: an inf in the cache would poison masked positions (0 * inf)
         d[0] = (_Float16)fminf(fmaxf(v.x, -lim), lim); d[1] = (_Float16)fminf(fmaxf(v.y, -lim), lim);
@@ -208,7 +213,7 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
     };
     if (t0 < nt) issue(t0);
     if (EPI == PF_QKV) {  // the epilogue's argument-block fields, fetched under the first DMA
-        ZG_PIN(qa.P); ZG_PIN(qa.E); ZG_PIN(qa.H); ZG_PIN(qa.ctx); ZG_PIN(qa.kv_f16); ZG_PIN(qa.k_cache); ZG_PIN(qa.v_cache);
+        ZG_PIN(qa.P); ZG_PIN(qa.E); ZG_PIN(qa.H); ZG_PIN(qa.ctx); ZG_PIN(qa.kv_mode); ZG_PIN(qa.kv_lo); ZG_PIN(qa.k_cache); ZG_PIN(qa.v_cache);
     }
 
     const int frow = lane & 31, fk = lane >> 5;

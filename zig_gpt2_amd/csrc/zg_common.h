@@ -53,6 +53,20 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
     return (uint16_t)(b >> 16);
 }
 
+// B24, the 24-bit KV cache element: the fp32 value rounded (nearest even) to 16 mantissa bits — sign, 8 exponent bits, the 15
+// upper mantissa bits — kept as a bf16-shaped upper half in one plane and the next 8 mantissa bits in a byte plane with the
+// same element index.  Relative error 2^-17 per element.  b24_round returns the 24 bits right-aligned.
+__device__ __forceinline__ uint32_t b24_round(float x) {
+    uint32_t b = __float_as_uint(x);
+    b += 0x7Fu + ((b >> 8) & 1u);
+    return b >> 8;
+}
+__device__ __forceinline__ void b24_store(void* cache, size_t lo_off, size_t elem, float x) {
+    const uint32_t r = b24_round(x);
+    reinterpret_cast<uint16_t*>(cache)[elem] = (uint16_t)(r >> 8);
+    reinterpret_cast<uint8_t*>(cache)[lo_off + elem] = (uint8_t)r;
+}
+
 // Two fp32 values -> packed bf16 pair (round to nearest even), one gfx950 instruction; lo half = a.
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     uint32_t r;

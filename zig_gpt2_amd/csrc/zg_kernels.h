@@ -54,7 +54,8 @@ struct GemvArgs {
     void* k_cache;
     void* v_cache;
     int ctx;
-    int kv_f16;
+    int kv_mode;   // 0 fp32, 1 fp16, 2 B24 (bf16 plane + byte plane `kv_lo` bytes further on)
+    size_t kv_lo;
     // EPI_ARGMAX: optional logits [M][logits_stride]; partials [M][gridDim.x]
     float* logits;
     int logits_stride;
@@ -133,7 +134,8 @@ struct AttnArgs {
     const void* k;   // element (b,h,t,d) at b*stride_b + h*stride_h + t*stride_t + d
     const void* v;
     long stride_b, stride_h, stride_t;
-    int kv_f16;
+    int kv_mode;   // 0 fp32, 1 fp16, 2 B24: bf16 plane at k / v, byte plane (same element strides) kv_lo bytes further on
+    size_t kv_lo;
     int n_heads, head_dim, batch;
     const StepCtrl* ctrl;  // seq_len read from ctrl->seq_len when non-null
     int seq_len;           // used when ctrl == nullptr
@@ -216,9 +218,10 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 // PF_QKV: fp32 store of the qkv rows (row m = b P + t) AND the cache append of ops.zig:152-157 for the K / V
 // columns, into the head-major caches [b][h][ctx][64] (fp32 or fp16).
 struct PrefillQkv {
-    int P, E, H, ctx, kv_f16;
+    int P, E, H, ctx, kv_mode;
     void* k_cache;
     void* v_cache;
+    size_t kv_lo;  // kv_mode 2: byte offset of the low-mantissa plane
 };
 struct PrefillLn {
     const float* g;

@@ -17,11 +17,12 @@ from .synth import GPTConfig
 
 class GPT:
     def __init__(self, config: GPTConfig, batch=1, weights_f32=False, use_graph=True, kv_f16=False, prefill=True,
-                 prefill_planes=3, prefetch=True):
+                 prefill_planes=3, prefetch=True, kv_b24=False):
         self.config, self.batch = config, batch
         L = _lib.load()
         flags = (_lib.GPT_WEIGHTS_F32 if weights_f32 else 0) | (0 if use_graph else _lib.GPT_NO_GRAPH)
         flags |= _lib.GPT_KV_F16 if kv_f16 else 0
+        flags |= _lib.GPT_KV_B24 if kv_b24 else 0
         flags |= 0 if prefill else _lib.GPT_NO_PREFILL
         flags |= _lib.GPT_PREFILL_2PLANE if prefill_planes == 2 else 0
         flags |= 0 if prefetch else _lib.GPT_NO_PREFETCH
