@@ -55,7 +55,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ---------------------------------------------------------------------------------------------------- geometry
 struct OV {
-    static constexpr int BM = 256, BN = 192;
+    static constexpr int BN = 192;  // (256-row tiles)
     static constexpr int A_SLOT = 256 * 128, B_SLOT = BN * 128;   // one K-step (64 of K) of the A / B tile
     static constexpr int A_OFF = 0, B_OFF = 2 * A_SLOT;           // [A slot 0][A slot 1][B slot 0][B slot 1]
     static constexpr int BIAS_OFF = 2 * A_SLOT + 2 * B_SLOT;      // two tiles' bias rows (fp32), by tile parity

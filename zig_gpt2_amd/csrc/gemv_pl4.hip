@@ -416,11 +416,21 @@ __global__ __launch_bounds__(256) void lm_head_wpt_kernel(const bf16_t* __restri
         int opaque = 0;
         asm volatile("" : "+v"(opaque));
         const char* ar = arow + opaque;
+        // the next tile of this wave streams in behind the current one: each pair of weight registers is reloaded as soon as
+        // its contents sit in the LDS slot, so a wave always has a whole tile (24 KB at K = 768) of loads in flight
+        const bool has_next = tile + 4 < tile_end;  // (wave-uniform)
+        const int nr0 = min(tile + 4, ntiles - 1) * 16 + lrow;
+        const bf16_t* np0 = W + (size_t)min(nr0, N - 1) * K + lpc * 8;
+        const bf16_t* np1 = W + (size_t)min(nr0 + 8, N - 1) * K + lpc * 8;
 #pragma unroll
         for (int j = 0; j < NS / 2; ++j) {
             char* sl = slot + (j & 1) * 2048;
             *reinterpret_cast<u32x4*>(sl + wr0) = wq[2 * j];
             *reinterpret_cast<u32x4*>(sl + wr1) = wq[2 * j + 1];
+            if (has_next) {
+                wq[2 * j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(np0 + j * 64));
+                wq[2 * j + 1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(np1 + j * 64));
+            }
             __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
             const mf_bf16x8 b0 = *reinterpret_cast<const mf_bf16x8*>(sl + rd0);
             const mf_bf16x8 b1 = *reinterpret_cast<const mf_bf16x8*>(sl + rd1);
@@ -435,7 +445,6 @@ __global__ __launch_bounds__(256) void lm_head_wpt_kernel(const bf16_t* __restri
         }
         const mf_f32x4 acc = acc0 + acc1;
         const int n = tile * 16 + brow;
-        if (tile + 4 < tile_end) load_tile(tile + 4);  // the next tile's weights fly under this tile's epilogue
         if (lane < 32 && n < N) {  // lanes 0..31 hold batch rows 0..7 (rows 8..15 of the tile alias them)
             const float bias_n = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll
