@@ -69,6 +69,33 @@ def test_b24_prefill_then_decode_matches_oracle(zg, name, batch, n):
     assert worst <= BOUND, worst
 
 
+@pytest.mark.parametrize("case", [(129, 257, 1, 4, 2), (300, 65, 2, 13, 7), (2049, 300, 1, 25, 1), (640, 50, 1, 20, 8)],
+                         ids=lambda c: "V%d_C%d_L%d_H%d_B%d" % c)
+def test_b24_irregular_shapes(zg, case):
+    """Head counts that are no powers of two (the byte plane sits behind batch * ctx * E bf16 elements), contexts of more
+    than one 256-position split, every writer (whole-prompt pass, then decode steps to the end of the context)."""
+    vocab, ctx, layers, heads, batch = case
+    cfg = synth.GPTConfig(vocab, ctx, layers, heads, 64 * heads)
+    seed = vocab * 3 + heads
+    m, w = make(cfg, seed, batch=batch, kv_b24=True)
+    n = max(ctx // 3, 2)
+    toks = np.stack([synth.rand_tokens(seed + 10 + b, ctx, vocab) for b in range(batch)])
+    lg = {n - 1: m.prefill(toks[:, :n]).copy()}
+    for s in range(n, ctx):
+        want = s in (n, n + 1, ctx // 2, ctx - 2, ctx - 1)
+        out = m.forward(s + 1, toks[:, s], compute_logits=want)
+        if want:
+            lg[s] = out.copy()
+    m.close()
+    worst = 0.0
+    for b in (0, batch - 1):
+        ref = oracle.GPT(cfg, w).forced_logits(toks[b], n - 1)
+        for s, v in lg.items():
+            worst = max(worst, dev(ref[s - (n - 1)], v[b]))
+    print(f"B24 {case}: worst deviation {worst:.2e} of the logit scale")
+    assert worst <= BOUND, worst
+
+
 def test_b24_124m_eight_prompts_full_context(zg):
     """configs[2]'s per-GPU load over the whole context: teacher-forced logits of the B24 handle against the
     fp32-cache handle on the same tokens, at positions spread over the 1024."""
