@@ -75,14 +75,14 @@ struct zg_gpt {
     // of every Block but the last — and the residual stream crosses between them as (value, tag) granules xg (GemvArgs.xg): the
     // kernel on the other stream is resident, its weights in flight, while its producer still runs, instead of starting behind
     // a kernel boundary (tools/microbench/two_graph_probe.hip: 4.31 -> 3.28 us per dependent 768 x 768 stage).
-    // B is itself two streams: ln_2 + c_fc on one, mlp c_proj on the other, gelu(c_fc) crossing as granules h4g.
+    // (A third stream — mlp c_proj on its own, gelu(c_fc) crossing as 4 E granules — was measured slower, 218.6-220.0 against
+    // 213.2-214.7 us per token, and removed: DESIGN 8.3.)
     bool dual_on;
-    int dual_parts;           // 2: mlp c_proj stays behind c_fc on the B stream (plain h4); 3: it has its own stream
-    unsigned long long *xg, *h4g;  // [E], [4 E] granules
-    unsigned* epoch2;         // step counters of the graphs: [0] A (advanced by the embed kernel), [64] B, [128] C (by bump kernels)
-    hipStream_t s2, s3;
-    hipEvent_t ev_fork, ev_join, ev_join3;
-    std::vector<hipGraphExec_t> graphs_b, graphs_kb, graphs_c, graphs_kc;  // the B / C parts of graphs / graphs_k
+    unsigned long long* xg;   // [E] granules
+    unsigned* epoch2;         // step counters of the graphs: [0] A (advanced by the embed kernel), [64] B (by a bump kernel)
+    hipStream_t s2;
+    hipEvent_t ev_fork, ev_join;
+    std::vector<hipGraphExec_t> graphs_b, graphs_kb;  // the B parts of graphs / graphs_k
     // LayerNorm statistics of x by 16-column tile, written by the producers of x (GemvArgs.st_out / st_in)
     float* xst;
     bool st_on;
@@ -193,7 +193,6 @@ void carve(zg_gpt* g, char* base) {
     g->epoch = (unsigned*)P(256);
     g->xst = (float*)P(((E + 15) / 16) * 8 * 2 * 4);
     g->xg = (unsigned long long*)P(E * 8);
-    g->h4g = (unsigned long long*)P(4 * E * 8);
     g->epoch2 = (unsigned*)P(1024);
     g->sk_tag_bytes = ((E + 15) / 16) * 4 * 128 * 8;
     g->part_tag_bytes = 8 * c.n_heads * g->max_splits * kPartStride * 8;
@@ -383,7 +382,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
     const bool dual = part >= 0;
     auto in_part = [&](size_t l, int k) {  // does kernel class k of Block l belong to this call?
         if (!dual) return true;
-        const int owner = (k == 4 && l + 1 < L) ? 1 : (k == 5 && l + 1 < L) ? g->dual_parts - 1 : 0;
+        const int owner = ((k == 4 || k == 5) && l + 1 < L) ? 1 : 0;
         return owner == part;
     };
     auto xg_common = [&](GemvArgs& a) {
@@ -517,14 +516,10 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 a.pl_out = g->hp;
                 a.y = nullptr;
             }
-            if (part == 1) {  // x from the A part's merge + c_proj of this Block; gelu(c_fc) to the C part as granules
+            if (part == 1) {  // x from the A part's merge + c_proj of this Block
                 xg_common(a);
                 a.xin_id = (unsigned)(2 + 2 * l);
                 a.xout_id = (unsigned)env_int("ZGPT2_DUAL_SLEEP", 4);
-                if (g->dual_parts == 3) {
-                    a.yg = g->h4g;
-                    a.yout_id = (unsigned)(1 + l);
-                }
             }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 4));
@@ -557,10 +552,6 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             }
             if (part >= 1) {  // input from the B part's c_fc; residual from the granules (that c_fc saw every tag); output to A
                 xg_common(a);
-                if (g->dual_parts == 3) {
-                    a.in_g = g->h4g;
-                    a.xin_id = (unsigned)(1 + l);
-                }
                 a.xg_resid = 1;
                 a.xout_id = (unsigned)(3 + 2 * l);
             }
@@ -670,7 +661,7 @@ int setup_prefetcher(zg_gpt* g) {
     if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || ctx().stream == nullptr) return ZG_OK;
     // the two-stream decode overlaps a kernel's weight fetch with its predecessor itself (and its launches do not pass the
     // one progress counter the prefetcher follows in order)
-    if (g->dual_on && !env_int("ZGPT2_DUAL_PREFETCH", 0)) return ZG_OK;
+    if (g->dual_on) return ZG_OK;  // (both together: 227-242 against 213 us per token)
     if (g->pf_njobs > 255) return ZG_OK;  // the progress word counts launches in 8 bits (n_layer >= 51): no prefetcher, not an error
     std::vector<PfJob> jobs;
     ZG_TRY(enqueue_step(g, true, (int)g->cfg.context_size, nullptr, nullptr, -1, 0, &jobs));
@@ -735,12 +726,9 @@ int pf_start(zg_gpt* g, size_t last_T, hipStream_t s) {
     a.max_T = (int)last_T;
     a.idle_limit = (unsigned)env_int("ZGPT2_PF_IDLE", 100000);  // polls without progress (~0.1 s) before it gives up
     a.sleep = (unsigned)env_int("ZGPT2_PF_SLEEP", 1);
-    a.xshift = (unsigned)env_int("ZGPT2_PF_XSHIFT", 0);
     a.cls_mask = (unsigned)env_int("ZGPT2_PF_CLASSES", 0x3e);  // lm_head's head start measured a net loss
-    a.line_shift = (unsigned)env_int("ZGPT2_PF_LINE", 7);
-    if (a.line_shift < 6 || a.line_shift > 7) a.line_shift = 7;
+    a.line_shift = 7;  // one touch per 128-byte line
     a.cap_bytes = (unsigned)env_int("ZGPT2_PF_CAP_KB", 0) << 10;
-    a.load_sc1 = (unsigned)env_int("ZGPT2_PF_SC1", 0);
     if (mode == 1) a.max_T = 0;
     if (a.lead < 1) a.lead = 1;
     if (a.nsub < 1) a.nsub = 1;
@@ -755,13 +743,10 @@ int pf_stop(zg_gpt* g, hipStream_t s) {
     return ZG_OK;
 }
 
-size_t prefill_min() {
-    static const long v = getenv("ZGPT2_PREFILL_MIN") ? atol(getenv("ZGPT2_PREFILL_MIN")) : 4;
-    return v > 0 ? (size_t)v : (size_t)-1;
-}
+size_t prefill_min() { return 4; }  // shorter prompts go through the decode chain (measured: the whole-prompt pass pays from 4 tokens up)
 
 void drop_graphs(zg_gpt* g) {
-    for (auto* v : {&g->graphs, &g->graphs_k, &g->graphs_b, &g->graphs_kb, &g->graphs_c, &g->graphs_kc})
+    for (auto* v : {&g->graphs, &g->graphs_k, &g->graphs_b, &g->graphs_kb})
         for (auto& e : *v)
             if (e) {
                 (void)hipGraphExecDestroy(e);
@@ -793,11 +778,9 @@ int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
     const bool with_logits = idx & 1;
     if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
     if (g->graphs_b.size() <= idx) g->graphs_b.resize(idx + 1, nullptr);
-    if (g->graphs_c.size() <= idx) g->graphs_c.resize(idx + 1, nullptr);
     if (g->graphs[idx]) return ZG_OK;
     const int t_hi = bucket_t_hi(g, seq_len);
     if (g->dual_on) ZG_TRY(capture_steps(g, &g->graphs_b[idx], with_logits, t_hi, 1, 1, g->s2));
-    if (g->dual_on && g->dual_parts == 3) ZG_TRY(capture_steps(g, &g->graphs_c[idx], with_logits, t_hi, 1, 2, g->s3));
     return capture_steps(g, &g->graphs[idx], with_logits, t_hi, 1, g->dual_on ? 0 : -1, s);
 }
 
@@ -806,11 +789,9 @@ int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
 int capture_multi(zg_gpt* g, size_t b, hipStream_t s) {
     if (g->graphs_k.size() <= b) g->graphs_k.resize(b + 1, nullptr);
     if (g->graphs_kb.size() <= b) g->graphs_kb.resize(b + 1, nullptr);
-    if (g->graphs_kc.size() <= b) g->graphs_kc.resize(b + 1, nullptr);
     if (g->graphs_k[b]) return ZG_OK;
     const int t_hi = bucket_t_hi(g, (b + 1) * 64);
     if (g->dual_on) ZG_TRY(capture_steps(g, &g->graphs_kb[b], true, t_hi, g->graph_steps, 1, g->s2));
-    if (g->dual_on && g->dual_parts == 3) ZG_TRY(capture_steps(g, &g->graphs_kc[b], true, t_hi, g->graph_steps, 2, g->s3));
     return capture_steps(g, &g->graphs_k[b], true, t_hi, g->graph_steps, g->dual_on ? 0 : -1, s);
 }
 
@@ -820,24 +801,18 @@ int dual_fork(zg_gpt* g, hipStream_t s) {
     if (!g->dual_on) return ZG_OK;
     ZG_HIP(hipEventRecord(g->ev_fork, s));
     ZG_HIP(hipStreamWaitEvent(g->s2, g->ev_fork, 0));
-    ZG_HIP(hipStreamWaitEvent(g->s3, g->ev_fork, 0));
     return ZG_OK;
 }
 int dual_join(zg_gpt* g, hipStream_t s) {
     if (!g->dual_on) return ZG_OK;
     ZG_HIP(hipEventRecord(g->ev_join, g->s2));
     ZG_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
-    ZG_HIP(hipEventRecord(g->ev_join3, g->s3));
-    ZG_HIP(hipStreamWaitEvent(s, g->ev_join3, 0));
     return ZG_OK;
 }
 // launch a captured step (or steps) on s — and its B half on the second stream
-int launch_graphs(zg_gpt* g, hipGraphExec_t a, hipGraphExec_t b, hipGraphExec_t c, hipStream_t s) {
+int launch_graphs(zg_gpt* g, hipGraphExec_t a, hipGraphExec_t b, hipStream_t s) {
     ZG_HIP(hipGraphLaunch(a, s));
-    if (g->dual_on) {
-        ZG_HIP(hipGraphLaunch(b, g->s2));
-        if (g->dual_parts == 3) ZG_HIP(hipGraphLaunch(c, g->s3));
-    }
+    if (g->dual_on) ZG_HIP(hipGraphLaunch(b, g->s2));
     return ZG_OK;
 }
 
@@ -866,7 +841,7 @@ int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
     if (g->graph_stream != s) ZG_TRY(capture_all(g, s));  // the caller switched streams after zg_gpt_create
     const size_t idx = ((seq_len + 63) / 64 - 1) * 2 + (with_logits ? 1 : 0);
     ZG_TRY(capture_bucket(g, idx, s));  // no-op: captured at create
-    return launch_graphs(g, g->graphs[idx], g->graphs_b[idx], g->graphs_c[idx], s);
+    return launch_graphs(g, g->graphs[idx], g->graphs_b[idx], s);
 }
 
 int upload_f32(const float* src, size_t n, void* dst, bool as_bf16, hipStream_t s) {
@@ -973,10 +948,10 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     // it has, so consumer + producer must fit the chip together — at GPT-2 XL ln_1 + c_attn alone is 600 workgroups of the
     // ~1024 that fit, and the producers queue behind the pollers until these give up (measured: every step timed out).
     g->dual_on = false;
-    g->s2 = g->s3 = nullptr;
-    g->ev_fork = g->ev_join = g->ev_join3 = nullptr;
+    g->s2 = nullptr;
+    g->ev_fork = g->ev_join = nullptr;
     if (batch == 1 && g->wt == WT_BF16 && c.n_layer >= 2 && c.n_layer <= 120 && !(flags & ZG_GPT_NO_GRAPH) && ctx().stream != nullptr &&
-        env_int("ZGPT2_DUAL", 0) && !env_int("ZGPT2_NO_DUAL", 0)) {  // measured at parity with the side-stream prefetcher: opt-in
+        env_int("ZGPT2_DUAL", 0)) {  // measured at parity with the side-stream prefetcher: opt-in
         const zg_layer& y = g->layers[0];
         const int t_top = (int)c.context_size;
         GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, t_top);
@@ -998,21 +973,16 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         g->dual_on = gemv_xg_ok(a1, g->wt) && gemv_xg_ok(a3, g->wt) && gemv_xg_ok(a4, g->wt) && gemv_xg_ok(a5, g->wt);
     }
     if (g->dual_on) {
-        // The three streams must sit on three different HARDWARE queues: two HIP streams that share one (the runtime deals its
-        // few queues round robin) execute in submission order, and a polling kernel queued in front of its producer never
-        // sees it run.  Streams of different priorities never share a queue: B runs above, C below the caller's stream.
+        // The two streams must sit on different HARDWARE queues: two HIP streams that share one (the runtime deals its few
+        // queues round robin) execute in submission order, and a polling kernel queued in front of its producer never sees it
+        // run.  Streams of different priorities never share a queue: B runs above the caller's stream.
         int prio_lo = 0, prio_hi = 0;
         hipError_t he2 = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        g->dual_parts = env_int("ZGPT2_DUAL_PARTS", 2) == 3 ? 3 : 2;
-        const int pswap = env_int("ZGPT2_DUAL_PRIO", 0);  // A/B: 0 = B high / C low, 1 = B low / C high
-        if (he2 == hipSuccess) he2 = hipStreamCreateWithPriority(&g->s2, hipStreamNonBlocking, pswap ? prio_lo : prio_hi);
-        if (he2 == hipSuccess) he2 = hipStreamCreateWithPriority(&g->s3, hipStreamNonBlocking, pswap ? prio_hi : prio_lo);
+        if (he2 == hipSuccess) he2 = hipStreamCreateWithPriority(&g->s2, hipStreamNonBlocking, prio_hi);
         if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
         if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
-        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_join3, hipEventDisableTiming);
         if (he2 == hipSuccess) he2 = hipMemsetAsync(g->epoch2, 0, 1024, ctx().stream);
         if (he2 == hipSuccess) he2 = hipMemsetAsync(g->xg, 0, c.n_embed * 8, ctx().stream);
-        if (he2 == hipSuccess) he2 = hipMemsetAsync(g->h4g, 0, 4 * c.n_embed * 8, ctx().stream);
         if (he2 == hipSuccess) he2 = hipStreamSynchronize(ctx().stream);
         if (he2 != hipSuccess) g->dual_on = false;  // (the single-stream step is always available)
     }
@@ -1089,14 +1059,11 @@ int zg_gpt_destroy(zg_gpt* g) {
     if (!g) return ZG_OK;
     (void)hipStreamSynchronize(ctx().stream);
     if (g->s2) (void)hipStreamSynchronize(g->s2);
-    if (g->s3) (void)hipStreamSynchronize(g->s3);
     drop_prefetcher(g);
     drop_graphs(g);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
     if (g->s2) (void)hipStreamDestroy(g->s2);
-    if (g->s3) (void)hipStreamDestroy(g->s3);
     (void)hipFree(g->arena);
     (void)hipHostFree(g->h_ctrl);
     (void)hipHostFree(g->h_ints);
@@ -1369,7 +1336,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
             if (g->graph_stream != s) rs = capture_all(g, s);
             const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
             if (rs == ZG_OK) rs = capture_multi(g, b, s);
-            if (rs == ZG_OK) rs = launch_graphs(g, g->graphs_k[b], g->graphs_kb[b], g->graphs_kc[b], s);
+            if (rs == ZG_OK) rs = launch_graphs(g, g->graphs_k[b], g->graphs_kb[b], s);
             st += K;
         } else {
             rs = run_step(g, st >= min_prompt, st + 1, s);

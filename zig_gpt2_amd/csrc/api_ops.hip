@@ -148,8 +148,7 @@ struct CallGuard {
 // result is fp32-sgemm grade (measured against the oracle at the reference's tolerance in the tests).
 // Order: small products first.
 static bool linear_mfma_ok(size_t in_f, size_t out_f, size_t m, size_t arena_left) {
-    static const bool off = getenv("ZGPT2_NO_LINEAR_MFMA") != nullptr;
-    if (off || m < 16 || in_f < 128 || in_f % 64 != 0) return false;
+    if (m < 16 || in_f < 128 || in_f % 64 != 0) return false;
     if (m * in_f * 3 >= (1u << 30) || out_f * in_f * 3 >= (1u << 30)) return false;
     // a ragged width (out_f % 4 != 0) is stored by the four-wave GEMM only, whose packed arguments end at K = 16384 per plane
     // and rows of 65535 elements (three planes side by side): such a Linear stays on the GEMV kernels

@@ -561,7 +561,9 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
         const long tiles = (long)((M + 255) / 256) * ((N + bn - 1) / bn);
         return ((tiles + 255) / 256) * bn;
     };
-    int bn = cost(192) < cost(256) ? 192 : 256;
+    // (ties and near-ties go to the 192-wide tiles: they run on the four-wave kernel, which is the faster generation —
+    // M = 16384: 76 us against 88.7 us on the eight-wave kernel's 256-wide tiles at equal cost)
+    int bn = cost(192) * 8 <= cost(256) * 9 ? 192 : 256;
     if (bn_env == 192 || bn_env == 256) bn = bn_env;
     ++g_gemm_launches;
     // Two generations of the kernel: the four-wave software-pipelined one (gemm_s4.hip) wherever 192-wide tiles are the

@@ -46,8 +46,7 @@ int gemv_lanes_per_row(int K) {
 // Wide, thin, un-normalised Linears of the lock-step batch (mlp c_proj) are cut into four K slices over as many
 // workgroups when the caller provided the combine workspace.
 int gemv_kslices(const GemvArgs& a) {
-    static const int off = getenv("ZGPT2_NO_SPLITK") ? atoi(getenv("ZGPT2_NO_SPLITK")) : 0;
-    if (off || a.sk_ws == nullptr || a.sk_cnt == nullptr || a.M < 2 || a.M > kMfmaRows) return 1;
+    if (a.sk_ws == nullptr || a.sk_cnt == nullptr || a.M < 2 || a.M > kMfmaRows) return 1;
     if (a.prologue != PRO_NONE || a.epilogue == EPI_ARGMAX || a.epilogue == EPI_QKV) return 1;
     if (a.K < 2048 || a.K % 128 != 0 || a.K / 4 > 3072 || (a.N + 15) / 16 > a.sk_tiles) return 1;
     return 4;
@@ -58,14 +57,13 @@ int gemv_kslices(const GemvArgs& a) {
 // The matrix-core path serves the model tier's lock-step batch: bf16 weights, 2..8 rows, K a
 // multiple of 32 whose three input planes fit in LDS, a fused LayerNorm no wider than 2048.
 bool gemv_use_mfma(const GemvArgs& a, int weight_type) {
-    static const int off = getenv("ZGPT2_NO_GEMV_MFMA") ? atoi(getenv("ZGPT2_NO_GEMV_MFMA")) : 0;
-    if (off || weight_type != WT_BF16 || a.M < 2 || a.M > kMfmaRows) return false;
+    if (weight_type != WT_BF16 || a.M < 2 || a.M > kMfmaRows) return false;
     if (gemv_kslices(a) > 1) return true;
     if (a.K % 32 != 0 || a.K / 32 < 4 || a.K / 32 > 96) return false;
     if (a.prologue == PRO_LAYERNORM && a.K > 2048) return false;
     if (gemv_mfma_lds(a.K, gemv_mfma_waves(a)) <= 160 * 1024) return true;
     // wide K: only as single-tile workgroups whose partial tiles alias the planes
-    static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
+    constexpr int wgs = 768;
     return a.epilogue != EPI_ARGMAX && (a.N + 15) / 16 <= wgs && gemv_mfma_lds(a.K, 16, true) <= 160 * 1024;
 }
 
@@ -103,7 +101,7 @@ int gemv_plan(GemvArgs& a, int weight_type) {
             a.rows_per_wave = lm_wpt_tiles_per_wg();
             return (ntiles + a.rows_per_wave - 1) / a.rows_per_wave;
         }
-        static const int wgs = getenv("ZGPT2_MFMA_WGS") ? atoi(getenv("ZGPT2_MFMA_WGS")) : 768;
+        constexpr int wgs = 768;
         int tpw = (ntiles + wgs - 1) / wgs;  // at most ~4 workgroups per CU for the widest matrices
         if (tpw < 1) tpw = 1;
         a.rows_per_wave = tpw;            // tiles per workgroup on this path
@@ -114,22 +112,14 @@ int gemv_plan(GemvArgs& a, int weight_type) {
     int rpw = (a.N + target_waves - 1) / target_waves;
     rpw = ((rpw + rpp2 - 1) / rpp2) * rpp2;
     if (rpw < rpp2) rpw = rpp2;
-    if (const char* e = getenv("ZGPT2_RPW")) {  // tuning experiments only
-        const int v = atoi(e);
-        if (v > 0 && a.N > 20000) rpw = v;
-    }
     a.rows_per_wave = rpw;
     const int waves = (a.N + rpw - 1) / rpw;
     // M == 1 without the argmax tail: one-wave workgroups while the matrix has at most ~8 waves per CU
-    static const int wpw_env = getenv("ZGPT2_WPW") ? atoi(getenv("ZGPT2_WPW")) : 0;
     int wpw = 4;
-    if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = wpw_env > 0 ? wpw_env : (waves <= 2048 ? 1 : 4);
-    static const int share_k = getenv("ZGPT2_SHARE_K") ? atoi(getenv("ZGPT2_SHARE_K")) : 2048;
-    static const int share_wpw = getenv("ZGPT2_SHARE_WPW") ? atoi(getenv("ZGPT2_SHARE_WPW")) : 0;
-    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= share_k && a.K <= 8192)
-        wpw = share_wpw > 0 ? share_wpw : 2;  // measured in situ: 2 >= 4 at K = 3072 (124M) and K = 6400 (XL)
-    static const int share_merge = getenv("ZGPT2_SHARE_MERGE") ? atoi(getenv("ZGPT2_SHARE_MERGE")) : 4;
-    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_ATTN_MERGE && share_merge > 1) wpw = share_merge;
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX) wpw = waves <= 2048 ? 1 : 4;
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_NONE && a.K >= 2048 && a.K <= 8192)
+        wpw = 2;  // measured in situ: 2 >= 4 at K = 3072 (124M) and K = 6400 (XL)
+    if (a.M == 1 && a.epilogue != EPI_ARGMAX && a.prologue == PRO_ATTN_MERGE) wpw = 4;
     a.waves_per_wg = wpw;
     return (waves + wpw - 1) / wpw;
 }
@@ -167,7 +157,7 @@ bool gemv_xg_ok(const GemvArgs& a, int weight_type) {
 }
 
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
-    ZG_REQUIRE((a.xg == nullptr && a.yg == nullptr && a.in_g == nullptr) || gemv_xg_ok(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: granule input / output asked of a launch outside the K-split kernels");
+    ZG_REQUIRE(a.xg == nullptr || gemv_xg_ok(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: granule input / output asked of a launch outside the K-split kernels");
     ZG_REQUIRE(a.pl_in == nullptr || gemv_planes_ok(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: input planes given to a launch outside the matrix-core path");
     ZG_REQUIRE(a.pl_out == nullptr || gemv_use_mfma(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: output planes asked of a launch outside the matrix-core path");
     if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);

@@ -140,10 +140,7 @@ __device__ __forceinline__ float epilogue_row(const GemvArgs& a, int m, int n, f
             break;
         case EPI_GELU:
             v = gelu_ref(v);
-            if (a.yg)  // two-stream decode: (value, tag) for the K-split kernel resident on another stream
-                __hip_atomic_store(a.yg + n, ((unsigned long long)((*a.epoch2 << 8) | a.yout_id) << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            else if (a.y) a.y[(size_t)m * a.y_stride + n] = v;  // null: the output leaves as planes only (GemvArgs.pl_out)
+            if (a.y) a.y[(size_t)m * a.y_stride + n] = v;  // null: the output leaves as planes only (GemvArgs.pl_out)
             break;
         case EPI_QKV: {
             const int E = a.N / 3;

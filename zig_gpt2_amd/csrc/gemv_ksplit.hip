@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
     const int epilogue = (int)(em & 0xffu), merge_splits = (int)((em >> 8) & 0xffu);
     const int has_bias = (int)((em >> 16) & 1u), has_resid = (int)((em >> 17) & 1u);
     const int xg_res = (int)((em >> 18) & 1u), xg_out = (int)((em >> 19) & 1u);  // two-stream decode: GemvArgs.xg
-    const int in_gran = (int)((em >> 20) & 1u);                                  // ... the input arrives as granules (xin = in_g)
     ZG_STAMP_DECL();
     ZG_STAMP(0);
     // merge_splits > 0 (attn c_proj): the input is the head merge of the attention partials — every lane combines
@@ -85,38 +84,6 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
             const float inv = 1.0f / l;
 #pragma unroll
             for (int j = 0; j < 8; ++j) xr[i].v[j] = r.v[j] * inv;
-        }
-    } else if (in_gran) {
-        // the input as (value, tag) granules from the LayerNorm-fed kernel on another stream (see gemv_lnk_kernel): the wave
-        // watches one granule of its K quarter, then every lane checks the chunks it multiplies
-        const unsigned want = (*a.epoch2 << 8) | a.xin_id;
-        const unsigned long long* gin = reinterpret_cast<const unsigned long long*>(xin);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (unsigned)K * 8u, 0x00020000);
-        unsigned spins = 0;
-        while ((unsigned)(__hip_atomic_load(gin + wave * Kq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != want && spins < a.spin_limit) {
-            __builtin_amdgcn_s_sleep(4);
-            ++spins;
-        }
-        for (;; ++spins) {
-            asm volatile("" ::: "memory");  // (plain intrinsics below: keep them inside the loop)
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                const unsigned off = ((unsigned)(wave * Kq) + (unsigned)min(lr + LPR * i, nchq - 1) * 8u) * 8u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32x4 gq = __builtin_amdgcn_raw_buffer_load_b128(rx, off + 16u * j, 0, 16);  // sc1
-                    ok = ok && gq.y == want && gq.w == want;
-                    xr[i].v[2 * j] = __uint_as_float(gq.x);
-                    xr[i].v[2 * j + 1] = __uint_as_float(gq.z);
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-            if (spins >= a.spin_limit) {
-                if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
         }
     } else {
 #pragma unroll
@@ -187,16 +154,15 @@ int launch_ksplit(const GemvArgs& a, hipStream_t s) {
     const int merge_splits = a.prologue == PRO_ATTN_MERGE ? (a.t_hi + kAttnChunk - 1) / kAttnChunk : 0;
     const unsigned has_resid = a.epilogue == EPI_RESIDUAL ? 1u : 0u;
     const unsigned xg_res = (a.xg && a.xg_resid && has_resid) ? 1u : 0u, xg_out = (a.xg && a.xout_id) ? 1u : 0u;
-    const unsigned in_gran = (a.in_g && merge_splits == 0) ? 1u : 0u;
     const unsigned em = (unsigned)a.epilogue | ((unsigned)merge_splits << 8) | ((a.bias ? 1u : 0u) << 16) | (has_resid << 17) | (xg_res << 18) |
-                        (xg_out << 19) | (in_gran << 20);
+                        (xg_out << 19);
     // two passes of 64 / LPR rows per workgroup (four measured slower: 2.65 -> 3.3 us for mlp c_proj)
 #define ZG_KS(LPR_, CPL_)                                                                                                \
     {                                                                                                                    \
         constexpr int rows = 2 * (64 / LPR_);                                                                            \
         note_kernel("gemv_ksplit_kernel<%s, %d, %d, 2>", sizeof(WT) == 2 ? "unsigned short" : "float", LPR_, CPL_);         \
         hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_, 2>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W,     \
-                           in_gran ? reinterpret_cast<const float*>(a.in_g) : a.x,                                      \
+                           a.x,                                                                                         \
                            a.N, a.K, em, a.part ? a.part : a.zero, a.max_splits, a.bias ? a.bias : a.zero,              \
                            (has_resid && !xg_res) ? a.resid : a.zero, a);                                                \
         ZG_HIP(hipGetLastError());                                                                                       \
@@ -452,19 +418,16 @@ int launch_lnk(const GemvArgs& a, hipStream_t s) {
 
 // M == 1 plain Linear over a wide input: the K-split kernel (measured against the shared-strip form in situ)
 bool gemv_use_ksplit(const GemvArgs& a) {
-    static const int off = getenv("ZGPT2_NO_KSPLIT") ? atoi(getenv("ZGPT2_NO_KSPLIT")) : 0;
-    static const int min_k = getenv("ZGPT2_KSPLIT_MIN_K") ? atoi(getenv("ZGPT2_KSPLIT_MIN_K")) : 2048;
-    if (off || a.M != 1) return false;
+    if (a.M != 1) return false;
     if (a.epilogue != EPI_STORE && a.epilogue != EPI_RESIDUAL && a.epilogue != EPI_GELU) return false;
     if (a.prologue == PRO_ATTN_MERGE)  // head merge folded into the lanes' own chunks: model tier, <= 4 splits known at launch
         return a.head_dim == 64 && a.t_hi > 0 && (a.t_hi + kAttnChunk - 1) / kAttnChunk <= 4 && a.K % 32 == 0 && a.K <= 1024;  // wider rows (XL, K = 1600: three chunks per lane) measured slower than the shared strip
     if (a.prologue != PRO_NONE) return false;
-    return a.K >= min_k && a.K % 32 == 0 && a.K / 32 <= 256;
+    return a.K >= 2048 && a.K % 32 == 0 && a.K / 32 <= 256;
 }
 
 bool gemv_use_lnk(const GemvArgs& a) {
-    static const int off = getenv("ZGPT2_NO_LNK") ? atoi(getenv("ZGPT2_NO_LNK")) : 0;
-    if (off || a.M != 1 || a.prologue != PRO_LAYERNORM || a.ln_c2 == nullptr || a.ln_c3 == nullptr) return false;
+    if (a.M != 1 || a.prologue != PRO_LAYERNORM || a.ln_c2 == nullptr || a.ln_c3 == nullptr) return false;
     if (a.epilogue != EPI_STORE && a.epilogue != EPI_GELU && a.epilogue != EPI_QKV) return false;
     return a.K % 32 == 0 && a.K / 32 <= 128 && a.N <= 16384;
 }

@@ -29,10 +29,6 @@ namespace {
 // One 4-byte load per 128-byte line: the line lands in this XCD's L2, the value is discarded.  A plain load: the
 // compiler waits for it only where the value is consumed (a `volatile` one is waited for on the spot).
 __device__ __forceinline__ unsigned touch(const char* p) { return *reinterpret_cast<const unsigned*>(p); }
-__device__ __forceinline__ unsigned touch_nt(const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)); }
-__device__ __forceinline__ unsigned touch_sc1(const char* p) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // Lines of job j that the blocks hosted by this XCD (b = mine, mine + 8, ...) of the upcoming launch will read; this
 // thread takes lines gt, gt + stride, ... of that set.  Loads are fire and forget: a value is consumed (so that the
@@ -45,11 +41,11 @@ struct Pending {
 #define ZG_PF_SLOT(u, cond, addr)                \
     {                                             \
         sink ^= pend.v[u];                        \
-        pend.v[u] = (cond) ? (sc1 == 1 ? touch_sc1(addr) : (sc1 == 2 ? touch_nt(addr) : touch(addr))) : 0u; \
+        pend.v[u] = (cond) ? touch(addr) : 0u;    \
     }
 
 __device__ __forceinline__ unsigned prefetch_job(const PfJob& j, unsigned mine, unsigned gt, unsigned stride, unsigned T, unsigned ls,
-                                                 unsigned cap_bytes, Pending& pend, unsigned sc1) {
+                                                 unsigned cap_bytes, Pending& pend) {
     unsigned sink = 0;
     if (j.kind == PF_WEIGHTS) {
 #pragma unroll
@@ -170,7 +166,7 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const PfArgs a) {
         const unsigned T = P >> 8, started = P & 255u;
         if (started == 0 || !(base & 0x100u)) continue;
         // block b of a launch runs on XCD (base + b) % 8: this XCD hosts the blocks b = mine - base (mod 8)
-        const unsigned mine = (xcd - base + a.xshift) & 7u;
+        const unsigned mine = (xcd - base) & 7u;
         const unsigned long long running = (unsigned long long)T * njobs + (started - 1u);
         if (cursor <= running) cursor = running + 1;
         const unsigned long long until = running + (unsigned)a.lead;
@@ -178,7 +174,7 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const PfArgs a) {
             const unsigned idx = (unsigned)(cursor % njobs);
             const unsigned Tj = (unsigned)(cursor / njobs);
             if (Tj <= (unsigned)a.max_T && ((a.cls_mask >> s_jobs[idx].cls) & 1u))
-                sink ^= prefetch_job(s_jobs[idx], mine, gt, stride, Tj, a.line_shift, a.cap_bytes, pend, a.load_sc1);
+                sink ^= prefetch_job(s_jobs[idx], mine, gt, stride, Tj, a.line_shift, a.cap_bytes, pend);
             ++cursor;
             ++jobs_done;
         }

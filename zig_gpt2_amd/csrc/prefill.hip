@@ -523,9 +523,8 @@ int launch_prefill_gemm_ns(const bf16_t* A, const bf16_t* B, const float* bias, 
 template <int EPI>
 int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
                           float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, int nsplit, hipStream_t s) {
-    static const int wide_env = getenv("ZGPT2_PF_WIDE") ? atoi(getenv("ZGPT2_PF_WIDE")) : -1;
     const int wide_tiles = ((M + BM - 1) / BM) * ((N + 2 * BN - 1) / (2 * BN));
-    const bool wide = wide_env >= 0 ? wide_env != 0 : (wide_tiles >= 256 && N >= 2 * BN);
+    const bool wide = wide_tiles >= 256 && N >= 2 * BN;
     if (wide) return launch_prefill_gemm_ns<EPI, 2>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, nsplit, s);
     return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, nsplit, s);
 }

@@ -100,11 +100,6 @@ struct GemvArgs {
     unsigned xin_id;          // != 0: poll until every input granule carries this id (0: the input is known to be complete)
     unsigned xout_id;         // != 0: the output row goes to xg with this id instead of y
     unsigned xg_resid;        // the residual is read from xg (value half, agent scope) instead of resid
-    // ... and the same for gelu(c_fc): the LayerNorm-fed kernel writes its output row as granules yg (tag id yout_id), the
-    // K-split kernel behind it reads its input from in_g, polling for xin_id
-    unsigned long long* yg;
-    unsigned yout_id;
-    const unsigned long long* in_g;
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
     unsigned* progress;       // launch counter followed by the side-stream prefetcher (prefetch.hip); null = not counted
 };
@@ -314,10 +309,8 @@ struct PfArgs {
     int max_T;          // last sequence length of the generation (nothing is fetched for steps beyond it)
     unsigned idle_limit;
     unsigned sleep;     // s_sleep(8) repetitions between polls
-    unsigned xshift;    // measurement: fetch the tiles of XCD (x + xshift) % 8 instead of the own ones
     unsigned cls_mask;  // bit c set: launches of class c are fetched for
     unsigned line_shift;  // log2 of the touch stride in bytes (7 = one load per 128-byte line)
-    unsigned load_sc1;    // measurement: agent-scope instead of plain loads
     unsigned cap_bytes;   // most bytes fetched for one launch (the head of every tile when the matrix is larger); 0 = no cap
 };
 int launch_prefetcher(const PfArgs& a, hipStream_t s);
