@@ -413,8 +413,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_gemm
 
-            gemm = bench_gemm.measure(lib, 8192)  # BASELINE's point; the other heights beside it (fewer launches each)
-            gemm["other_M"] = [{k: v for k, v in bench_gemm.measure(lib, m, iters=20, batches=3, warm=100).items()
+            gemm = bench_gemm.measure(lib, 8192)  # BASELINE's point; the other heights beside it (same warm-up: the clocks need it)
+            gemm["other_M"] = [{k: v for k, v in bench_gemm.measure(lib, m).items()
                                 if k in ("M", "us", "us_min", "tflops", "mfma_frac_of_2.5PF")} for m in (1024, 16384)]
             _lib.check(lib.zg_set_stream(stream.cuda_stream))
         except Exception as e:  # the headline metric must not die with the secondary one

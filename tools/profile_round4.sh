@@ -26,6 +26,7 @@ pmc() {
 python bench.py --steps 5 --warmup 1 > $out/${tag}_bench.json 2> $out/bench.err
 python bench.py --steps 3 --warmup 1 --prompts-per-gpu 8 --no-cpu-baseline > $out/${tag}_bench_8prompts.json 2> $out/bench_8prompts.err
 python bench.py --steps 3 --warmup 1 --prompts-per-gpu 8 --kv-f16 --no-cpu-baseline > $out/${tag}_bench_8prompts_kvf16.json 2> $out/bench_8prompts_kvf16.err
+python bench.py --steps 3 --warmup 1 --prompts-per-gpu 8 --kv-b24 --no-cpu-baseline > $out/${tag}_bench_8prompts_kvb24.json 2> $out/bench_8prompts_kvb24.err
 python bench.py --steps 3 --warmup 1 --weights-f32 --no-cpu-baseline > $out/${tag}_bench_weights_f32.json 2> $out/bench_weights_f32.err
 ZGPT2_DUAL=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $out/${tag}_bench_dual.json 2> $out/bench_dual.err
 trace 124m python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs
@@ -34,7 +35,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc 124m_8prompts $c python3 tools/pmc_decode.py 124M 8
   pmc xl $c python3 tools/pmc_decode.py xl 1
 done
-for n in 124m_8prompts xl; do cp profiles/round3_${n}_kernel_stats.md $out/${tag}_${n}_kernel_stats.md 2>/dev/null; done
+trace 124m_8prompts python3 bench.py --steps 2 --warmup 1 --prompts-per-gpu 8 --no-cpu-baseline
+trace xl python3 bench.py --model xl --steps 1 --warmup 1 --no-cpu-baseline
 python tools/make_traffic_json.py $out $tag > /dev/null 2> $out/traffic.err
 ZGPT2_GEMM_KERNEL=s4 trace gemm_s4 python3 tools/bench_gemm.py 8192
 : > $out/${tag}_gemm_s4_pmc.md
@@ -45,6 +47,8 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY
   rm -rf $out/pg_$n
 done
 { ZGPT2_GEMM_DBG=256 tools/bin/gemm_bench -k s4 -stamps; tools/bin/gemm_bench -k p8 -nocheck; ZGPT2_GEMM_DBG=256 tools/bin/gemm_bench 16384 3072 768 -k s4 -stamps -nocheck; } > $out/${tag}_gemm_bench.txt 2>&1
+for m in 1024 4096 8192 12288 16384 32768; do python tools/bench_gemm.py $m 2>/dev/null | tail -1; done > $out/${tag}_gemm_by_m.jsonl
+tools/bin/paired_mlp_probe 768 12 300 > $out/${tag}_paired_mlp_probe.txt 2>&1
 python tools/bench_prefill.py > $out/${tag}_prefill.jsonl 2> $out/prefill.err
 python tools/bench_prefill.py --batch 8 --lengths 128,1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
 python tools/bench_prefill.py --planes 2 --lengths 128,1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
