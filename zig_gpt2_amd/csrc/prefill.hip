@@ -171,7 +171,7 @@ template <int EPI, int NS, int NSPL>  // NS 64-column strips per wave: the tile 
 __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
                                                   void* __restrict__ C, int M, int N, int K, int ldc, unsigned tp, int n_tiles,
                                                   const PrefillQkv& qa, const int sp, const int slab) {
-    // tp = tiles_n | split-K slices << 12 | activation planes << 24: the 14 preloaded argument dwords carry everything the
+    // tp = tiles_n | split-K slices << 12 | rows of the XCD grid << 24: the 14 preloaded argument dwords carry everything the
     // first DMA depends on (zg_common.h ZG_PIN; gridDim is a scalar load from the kernarg segment)
     const int tiles_n = (int)(tp & 0xfffu);
     constexpr int nsplit = NSPL;
@@ -183,9 +183,26 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
     const int n_sp = (int)((tp >> 12) & 0xfffu);  // split-K slices (PF_PARTIAL only; otherwise 1)
-    const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = bid & 7, loc = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    // Workgroups are dealt round robin over the eight XCDs, each with its own L2: XCD x gets workgroups x, x + 8, ...  Which tiles
+    // those are decides what every L2 has to fetch.  gr != 0 (tp bits 24-27; the tile counts divide): the XCDs form a gr x 8 / gr
+    // grid of equal blocks of tiles_m / gr x tiles_n / (8 / gr) tiles, so an XCD reads that many row tiles of the activation planes
+    // and that many column tiles of the weights (c_fc at 1023 tokens, 8 x 24 tiles: 2 x 12 per XCD = 1.2 + 2.4 MB through a 4-MB L2,
+    // where one row tile against ALL of W was 0.6 + 4.7 MB: FETCH per launch 32.6 -> 23.4 MB, c_attn 41.8 -> 27.9 MB; the time did not
+    // move — 1.50 against 1.52 ms per 1023-token prompt — the loop is not fetch-bound: profiles/round4_prefill_xcd_blocks.txt).  gr == 0: contiguous ranges of the row-major
+    // tile order.
+    const int xcd = bid & 7, loc = bid >> 3, gr = (int)((tp >> 24) & 0xfu);
+    int tm, tn;
+    if (gr == 0) {
+        const int q8 = n_tiles >> 3, r8 = n_tiles & 7;
+        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        tm = tile / tiles_n;
+        tn = tile % tiles_n;
+    } else {
+        const int gc = 8 / gr, cp = tiles_n / gc, rp = (n_tiles / tiles_n) / gr;
+        const int xr = xcd / gc, xc = xcd - xr * gc, lr_ = loc / cp;
+        tm = xr * rp + lr_;
+        tn = xc * cp + (loc - lr_ * cp);
+    }
     constexpr int BNT = BN * NS, NJ = 2 * NS, kStageB = stage_bytes(NS), kBBytes = NS * kTileBytes;
     const int m0 = tm * BM, n0 = tn * BNT;
 
@@ -436,6 +453,24 @@ __global__ __launch_bounds__(256) void prefill_reduce_resid_ln_kernel(const floa
     }
 }
 
+// Rows of the XCD grid for a tiles_m x tiles_n launch (prefill_gemm_body): the divisor pair that makes an XCD's L2 fetch the
+// fewest bytes — a_tile / w_tile = bytes of one row tile of the activation planes / one column tile of the weights; 0 = no pair
+// divides both tile counts (contiguous ranges then).
+static unsigned xcd_grid_rows(int tiles_m, int tiles_n, size_t a_tile, size_t w_tile) {
+    unsigned best = 0;
+    size_t best_cost = 0;
+    for (int gr = 1; gr <= 8; gr *= 2) {
+        const int gc = 8 / gr;
+        if (tiles_m % gr != 0 || tiles_n % gc != 0) continue;
+        const size_t cost = (size_t)(tiles_m / gr) * a_tile + (size_t)(tiles_n / gc) * w_tile;
+        if (best == 0 || cost < best_cost) {
+            best = (unsigned)gr;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 template <int EPI, int NS, int NSPL>
 int launch_prefill_gemm_np(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc,
                            float* ws, size_t ws_floats, const PrefillLn* ln, const PrefillQkv& qa, hipStream_t s) {
@@ -458,12 +493,14 @@ int launch_prefill_gemm_np(const bf16_t* A, const bf16_t* B, const float* bias, 
     while (n_sp > 1 && (size_t)n_sp * M * N > ws_floats) --n_sp;
     static const int force = getenv("ZGPT2_PF_SPLITK") ? atoi(getenv("ZGPT2_PF_SPLITK")) : 0;
     if (force > 0) n_sp = force;
+    const unsigned xg = xcd_grid_rows(tiles_m, tiles_n, (size_t)BM * (K / (n_sp > 1 && ws ? n_sp : 1)) * 2 * nsplit,
+                                      (size_t)BN * NS * (K / (n_sp > 1 && ws ? n_sp : 1)) * 2);
     if (n_sp <= 1 || !ws) {
         hipLaunchKernelGGL((prefill_gemm_kernel<EPI, NS, NSPL>), dim3(tiles), dim3(256), lds_bytes(NS), s, A, B, bias, C, M, N, K,
-                           ldc, (unsigned)tiles_n | (1u << 12) | ((unsigned)nsplit << 24), tiles, qa);
+                           ldc, (unsigned)tiles_n | (1u << 12) | (xg << 24), tiles, qa);
     } else {
         hipLaunchKernelGGL((prefill_gemm_kernel<PF_PARTIAL, NS, NSPL>), dim3(tiles, n_sp), dim3(256), lds_bytes(NS), s, A, B, bias,
-                           (void*)ws, M, N, K, ldc, (unsigned)tiles_n | ((unsigned)n_sp << 12) | ((unsigned)nsplit << 24), tiles, qa);
+                           (void*)ws, M, N, K, ldc, (unsigned)tiles_n | ((unsigned)n_sp << 12) | (xg << 24), tiles, qa);
         if (EPI == PF_RESID && ln && ldc == N && N <= 2048) {
             hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, n_sp, bias,
                                reinterpret_cast<float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out);
@@ -495,8 +532,9 @@ int launch_prefill_gemm_wp(const bf16_t* A, const bf16_t* B, const float* bias, 
     if (n_sp < 1) n_sp = 1;
     while (n_sp > 1 && (size_t)3 * n_sp * M * N > ws_floats) --n_sp;
     ZG_REQUIRE(ws && (size_t)3 * n_sp * M * N <= ws_floats, ZG_ERR_ARG, "prefill GEMM (fp32 weights): workspace of %zu floats for %d x %d", ws_floats, M, N);
+    const unsigned xg = xcd_grid_rows(tiles_m, tiles_n, (size_t)BM * (K / n_sp) * 2 * 3, (size_t)BN * NS * (K / n_sp) * 2);
     hipLaunchKernelGGL((prefill_gemm_wp_kernel<NS>), dim3(tiles, 3 * n_sp), dim3(256), lds_bytes(NS), s, A, B, bias, (void*)ws, M, N, K, ldc,
-                       (unsigned)tiles_n | ((unsigned)n_sp << 12), tiles, qa);
+                       (unsigned)tiles_n | ((unsigned)n_sp << 12) | (xg << 24), tiles, qa);
     if (EPI == PF_RESID && ln && ldc == N && N <= 2048) {
         hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, 3 * n_sp, bias, reinterpret_cast<float*>(C), M, N, ln->g,
                            ln->b, ln->eps, ln->out);
