@@ -152,6 +152,19 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld,
     }
 }
 
+// one piece q (0 .. PPW - 1) of the above
+template <int PPW = 4>
+__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ G, int ld, int row0, int rows, int k0, char* lds_tile, int wave,
+                                            int lane, int q) {
+    const int piece = wave * PPW + q;
+    const int row = piece * 8 + (lane >> 3);
+    const int pos = lane & 7;
+    const int chunk = pos ^ ((row >> 1) & 7);
+    const int grow = min(row0 + row, rows - 1);
+    const bf16_t* src = G + (size_t)grow * ld + k0 + chunk * 8;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+}
+
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
     const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
     return *reinterpret_cast<const bf16x8*>(lds_tile + off);
@@ -167,6 +180,21 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // [M][3N] split planes (PF_GELU_SPLIT).  N % 64 == 0, K % 64 == 0, any M.
 // (the body is shared by prefill_gemm_kernel and prefill_gemm_wp_kernel: sp = K slice of this workgroup, slab = the partial
 // slab it writes under PF_PARTIAL)
+#ifdef ZG_PF_STAMPS  // diagnostic build only (tools/pf_stamps.py): where one wave of a prompt GEMM spends its K loop
+__device__ unsigned long long g_pf_stamps[32];
+#define ZG_PFS(i, expr)                                                            \
+    do {                                                                           \
+        if (pfs_on) {                                                              \
+            const unsigned long long t_ = __builtin_readcyclecounter();            \
+            expr;                                                                  \
+            pfs[i] += __builtin_readcyclecounter() - t_;                           \
+        } else {                                                                   \
+            expr;                                                                  \
+        }                                                                          \
+    } while (0)
+#else
+#define ZG_PFS(i, expr) expr
+#endif
 template <int EPI, int NS, int NSPL>  // NS 64-column strips per wave: the tile is 128 x (128 NS); NSPL activation planes multiplied
 __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
                                                   void* __restrict__ C, int M, int N, int K, int ldc, unsigned tp, int n_tiles,
@@ -228,16 +256,40 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
         for (int p = 0; p < kSplit; ++p)
             if (p < nsplit) stage_tile(A, kSplit * K, m0, M, p * K + t * BK, slot + kBBytes + p * kTileBytes, wave, lane);
     };
+    // ... and piece by piece: the K loop deals the pieces of the next stage over its first MFMA groups instead of issuing all of
+    // them at the barrier (their LDS writes then met the first fragment reads of the step in one burst: MFMAs + fragment reads
+    // alone 7.7 us, DMA alone 5.7 us, together 21.7 us per c_fc launch)
+    constexpr int NPC = 4 * NS + 4 * NSPL;  // pieces per wave and K-step
+    auto issue_piece = [&](int t, int idx) {
+        char* slot = lds + ((t - t0) & 1) * kStageB;
+        if (idx < 4 * NS) stage_piece<4 * NS>(B, K, n0, N, t * BK, slot, wave, lane, idx);
+        else {
+            const int p = (idx - 4 * NS) >> 2, q = (idx - 4 * NS) & 3;
+            stage_piece<4>(A, kSplit * K, m0, M, p * K + t * BK, slot + kBBytes + p * kTileBytes, wave, lane, q);
+        }
+    };
     if (t0 < nt) issue(t0);
     if (EPI == PF_QKV) {  // the epilogue's argument-block fields, fetched under the first DMA
         ZG_PIN(qa.P); ZG_PIN(qa.E); ZG_PIN(qa.H); ZG_PIN(qa.ctx); ZG_PIN(qa.kv_mode); ZG_PIN(qa.kv_lo); ZG_PIN(qa.k_cache); ZG_PIN(qa.v_cache);
     }
 
     const int frow = lane & 31, fk = lane >> 5;
+#ifdef ZG_PF_STAMPS
+    const bool pfs_on = blockIdx.x == 8 && blockIdx.y == 0 && wave == 0;
+    unsigned long long pfs[4] = {0, 0, 0, 0};
+    const unsigned long long pfs_t0 = __builtin_readcyclecounter();
+#endif
     for (int t = t0; t < nt; ++t) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of stage t landed
-        __builtin_amdgcn_s_barrier();        // everyone's did, and nobody still reads the other slot
-        if (t + 1 < nt) issue(t + 1);
+        ZG_PFS(0, __builtin_amdgcn_s_waitcnt(0x0f70));  // vmcnt(0): this wave's pieces of stage t landed
+        ZG_PFS(1, __builtin_amdgcn_s_barrier());        // everyone's did, and nobody still reads the other slot
+        // (`more` is tested per piece — a uniform branch between two MFMAs.  Two copies of the body, with and without the pieces,
+        // were measured: the compiler then keeps the accumulators in VGPRs across the loop and moves all 64 to the accumulation
+        // file and back around the MFMAs of every step — 3257 against 2817 cycles per K-step.)
+#if defined(ZG_PF_ABL) && (ZG_PF_ABL & 1)
+        const bool more = false;  // ablation: no LDS-DMA in the loop (stale operands)
+#else
+        const bool more = t + 1 < nt;
+#endif
         const char* cur = lds + ((t - t0) & 1) * kStageB;
         // 12 groups (16-k slice kk, plane p = 2, 1, 0: smallest plane first) of 2 NJ MFMAs.  The fragments of group g + 1 are
         // read IN FRONT of group g's MFMAs (two register sets, sched barriers pin the order): with one wave per SIMD nothing
@@ -247,61 +299,74 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
         // the prefetched ones included — in front of every group.)
         // The reads are hand-issued (asm) with COUNTED waits: left to itself the compiler waits for lgkmcnt(0) in front of
         // every second group, i.e. also for the reads it has just issued for the group after.
-        bf16x8 bq[2][NJ], aq[2][2];
+        bf16x8 bq[2][NJ], aq[2][NSPL][2];
         const unsigned cur_a = (unsigned)(unsigned long)(lds_ptr_t)cur;
         auto rd = [&](bf16x8& dst, unsigned tile_off, int row, int chunk) {
             const unsigned addr = cur_a + tile_off + (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
             asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
         };
-        auto rd_b = [&](int kk, bf16x8(&b)[NJ]) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) rd(b[j], 0u, wn * 64 * NS + j * 32 + frow, kk * 2 + fk);
-        };
-        auto rd_a = [&](int kk, int p, bf16x8(&a)[2]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) rd(a[i], (unsigned)(kBBytes + p * kTileBytes), wm * 64 + i * 32 + frow, kk * 2 + fk);
-        };
-        rd_b(0, bq[0]);
-        rd_a(0, NSPL - 1, aq[0]);
-#pragma unroll
-        for (int g = 0; g < 4 * NSPL; ++g) {
-            const int kk = g / NSPL;
-            int n_next = 0;  // reads issued for group g + 1: still in flight when group g multiplies
-            if (g + 1 < 4 * NSPL) {
-                const int kk1 = (g + 1) / NSPL, p1 = NSPL - 1 - (g + 1) % NSPL;
-                if (kk1 != kk) {
-                    rd_b(kk1, bq[kk1 & 1]);
-                    n_next += NJ;
-                }
-                rd_a(kk1, p1, aq[(g + 1) & 1]);
-                n_next += 2;
+        // fragment r of 16-k slice kk, in the order the slice uses them: the NJ weight-row fragments of the wave's columns, then
+        // its two row fragments of every plane, smallest plane first
+        constexpr int RS = NJ + 2 * NSPL;   // fragment reads per slice
+        constexpr int MS = 2 * NJ * NSPL;   // MFMAs per slice
+        constexpr int RSLOT = (RS + 1) / 2; // MFMAs of a slice that carry two reads of the next slice each
+        auto rd_item = [&](int kk, int r, bf16x8(&bb)[NJ], bf16x8(&aa)[NSPL][2]) {
+            if (r < NJ) rd(bb[r], 0u, wn * 64 * NS + r * 32 + frow, kk * 2 + fk);
+            else {
+                const int pi = (r - NJ) >> 1, i = (r - NJ) & 1, p = NSPL - 1 - pi;
+                rd(aa[p][i], (unsigned)(kBBytes + p * kTileBytes), wm * 64 + i * 32 + frow, kk * 2 + fk);
             }
-            // The wait names group g's fragments as read-write operands: for the compiler they are ready straight behind the
+        };
+#pragma unroll
+        for (int r = 0; r < RS; ++r) rd_item(0, r, bq[0], aq[0]);  // the step's first slice: in one burst behind the barrier
+        // One instruction stream per wave, nothing else on its SIMD: whatever the wave issues between two MFMAs runs in the 32
+        // cycles the matrix pipe is busy with the first, and whatever it issues in a burst leaves the pipe idle.  Stamps and
+        // ablations of the loop (tools/pf_stamps.py, -DZG_PF_ABL) priced the bursts of the first version per K-step of 48 MFMAs
+        // = 1536 cycles: the 16 LDS-DMA pieces issued in groups of 2-3 behind MFMA groups +540 cycles, the fragment reads of a
+        // slice issued in front of its MFMAs +130, on a bare loop of ~1950 (barrier, first slice's read latency).  Now every MFMA
+        // carries at most two fragment reads of the NEXT slice (the first RSLOT MFMAs of a slice: the last read then has more
+        // than 250 cycles of cover) or one LDS-DMA piece of the next stage (the MFMAs behind them, earliest slices first); the
+        // wait in front of a slice is lgkmcnt(0) — everything older is that slice's fragments.  Same MFMA order as before.
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cb = kk & 1;
+            // The wait names slice kk's fragments as read-write operands: for the compiler they are ready straight behind the
             // read statements, and only an operand tie keeps a copy, coalesce or spill of those registers from being placed in
             // front of the wait (sched_barrier pins instruction order, not what register allocation inserts).
-#define ZG_WAIT_FRAGS(N)                                                                                                                          \
-    do {                                                                                                                                          \
-        if constexpr (NJ == 2)                                                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(aq[g & 1][0]), "+v"(aq[g & 1][1]), "+v"(bq[kk & 1][0]), "+v"(bq[kk & 1][NJ - 1])::"memory"); \
-        else                                                                                                                                      \
-            asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                              \
-                         : "+v"(aq[g & 1][0]), "+v"(aq[g & 1][1]), "+v"(bq[kk & 1][0]), "+v"(bq[kk & 1][1]), "+v"(bq[kk & 1][NJ > 2 ? 2 : 0]),       \
-                           "+v"(bq[kk & 1][NJ - 1])::"memory");                                                                                   \
-    } while (0)
-            if (n_next == 0) ZG_WAIT_FRAGS(0);
-            else if (n_next == 2) ZG_WAIT_FRAGS(2);
-            else if (n_next == 2 + NJ && NJ == 2) ZG_WAIT_FRAGS(4);
-            else ZG_WAIT_FRAGS(6);
-#undef ZG_WAIT_FRAGS
+#define ZG_TIE2(x) "+v"(x[0]), "+v"(x[1])
+#define ZG_TIE4(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[NJ > 2 ? 2 : 0]), "+v"(x[NJ > 2 ? 3 : 1])
+            if constexpr (NSPL == 3 && NJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : ZG_TIE2(aq[cb][0]), ZG_TIE2(aq[cb][1]), ZG_TIE2(aq[cb][2]), ZG_TIE2(bq[cb])::"memory");
+            else if constexpr (NSPL == 3) asm volatile("s_waitcnt lgkmcnt(0)" : ZG_TIE2(aq[cb][0]), ZG_TIE2(aq[cb][1]), ZG_TIE2(aq[cb][2]), ZG_TIE4(bq[cb])::"memory");
+            else if constexpr (NSPL == 2 && NJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : ZG_TIE2(aq[cb][0]), ZG_TIE2(aq[cb][1]), ZG_TIE2(bq[cb])::"memory");
+            else if constexpr (NSPL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : ZG_TIE2(aq[cb][0]), ZG_TIE2(aq[cb][1]), ZG_TIE4(bq[cb])::"memory");
+            else if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : ZG_TIE2(aq[cb][0]), ZG_TIE2(bq[cb])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : ZG_TIE2(aq[cb][0]), ZG_TIE4(bq[cb])::"memory");
+#undef ZG_TIE4
+#undef ZG_TIE2
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[g & 1][i], bq[kk & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < MS; ++m) {
+                const int pi = m / (2 * NJ), i = (m / NJ) & 1, j = m % NJ, p = NSPL - 1 - pi;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cb][p][i], bq[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < RSLOT) {
+#if !(defined(ZG_PF_ABL) && (ZG_PF_ABL & 2))
+                    if (kk + 1 < 4) {
+                        rd_item(kk + 1, 2 * m, bq[cb ^ 1], aq[cb ^ 1]);
+                        if (2 * m + 1 < RS) rd_item(kk + 1, 2 * m + 1, bq[cb ^ 1], aq[cb ^ 1]);
+                    }
+#endif
+                } else {
+                    const int piece = kk * (MS - RSLOT) + (m - RSLOT);
+                    if (piece < NPC && more) issue_piece(t + 1, piece);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
+#ifdef ZG_PF_STAMPS
+    const unsigned long long pfs_t1 = __builtin_readcyclecounter();
+#endif
     __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
 
     // epilogue: each 64 x 64 fp32 strip of the wave goes through LDS so that global accesses are 16-B row segments
@@ -343,6 +408,16 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
             }
         }
     }
+#ifdef ZG_PF_STAMPS
+    if (pfs_on && lane == 0) {
+        g_pf_stamps[0] = (unsigned long long)(nt - t0);
+        g_pf_stamps[1] = pfs[0];
+        g_pf_stamps[2] = pfs[1];
+        g_pf_stamps[3] = pfs_t1 - pfs_t0;                       // the K loop
+        g_pf_stamps[4] = __builtin_readcyclecounter() - pfs_t1;  // barrier + epilogue
+        g_pf_stamps[5] = (unsigned long long)EPI;
+    }
+#endif
 }
 
 template <int EPI, int NS, int NSPL = kSplit>
@@ -797,4 +872,15 @@ int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int 
     return ZG_OK;
 }
 
+#ifdef ZG_PF_STAMPS
+}  // namespace zg
+extern "C" int zg_debug_prefill_stamps(unsigned long long* out, size_t n) {
+    unsigned long long h[32];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(zg::g_pf_stamps), sizeof h) != hipSuccess) return -1;
+    for (size_t i = 0; i < n && i < 32; ++i) out[i] = h[i];
+    return 0;
+}
+namespace zg {
+#endif
 }  // namespace zg
