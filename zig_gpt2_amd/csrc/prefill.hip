@@ -136,35 +136,6 @@ constexpr int kStages = 2;
 constexpr int stage_bytes(int ns) { return (ns + kSplit) * kTileBytes; }
 constexpr int lds_bytes(int ns) { return kStages * stage_bytes(ns); }  // 128 / 160 KiB; reused as store staging
 
-// rows beyond `rows` are clamped to the last valid row (loaded, never stored)
-template <int PPW = 4>  // 1-KiB pieces (8 rows x 128 B) per wave: 4 for a 128-row tile, 8 for 256 rows
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int rows, int k0, char* lds_tile,
-                                           int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        const int piece = wave * PPW + q;
-        const int row = piece * 8 + (lane >> 3);
-        const int pos = lane & 7;
-        const int chunk = pos ^ ((row >> 1) & 7);
-        const int grow = min(row0 + row, rows - 1);
-        const bf16_t* src = G + (size_t)grow * ld + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-
-// one piece q (0 .. PPW - 1) of the above
-template <int PPW = 4>
-__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ G, int ld, int row0, int rows, int k0, char* lds_tile, int wave,
-                                            int lane, int q) {
-    const int piece = wave * PPW + q;
-    const int row = piece * 8 + (lane >> 3);
-    const int pos = lane & 7;
-    const int chunk = pos ^ ((row >> 1) & 7);
-    const int grow = min(row0 + row, rows - 1);
-    const bf16_t* src = G + (size_t)grow * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
-}
-
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
     const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
     return *reinterpret_cast<const bf16x8*>(lds_tile + off);
@@ -202,7 +173,6 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
     // tp = tiles_n | split-K slices << 12 | rows of the XCD grid << 24: the 14 preloaded argument dwords carry everything the
     // first DMA depends on (zg_common.h ZG_PIN; gridDim is a scalar load from the kernarg segment)
     const int tiles_n = (int)(tp & 0xfffu);
-    constexpr int nsplit = NSPL;
     // nsplit = activation planes multiplied: 3 = exact fp32 activations (hi + mid + lo), 2 = hi + mid only
     // (2^-17 relative per activation, ~2e-5 of the logit scale end to end: inside north_star's 1e-3, outside the
     // strict near-zero floor of the tests; 2/3 of the matrix work)
@@ -249,24 +219,43 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
     // Split-K slice sp takes the K-steps [t0, nt).
     const int nk = K / BK;
     const int t0 = (int)((long)nk * sp / n_sp), nt = (int)((long)nk * (sp + 1) / n_sp);
-    auto issue = [&](int t) {
-        char* slot = lds + ((t - t0) & 1) * kStageB;
-        stage_tile<4 * NS>(B, K, n0, N, t * BK, slot, wave, lane);
-#pragma unroll
-        for (int p = 0; p < kSplit; ++p)
-            if (p < nsplit) stage_tile(A, kSplit * K, m0, M, p * K + t * BK, slot + kBBytes + p * kTileBytes, wave, lane);
-    };
-    // ... and piece by piece: the K loop deals the pieces of the next stage over its first MFMA groups instead of issuing all of
-    // them at the barrier (their LDS writes then met the first fragment reads of the step in one burst: MFMAs + fragment reads
-    // alone 7.7 us, DMA alone 5.7 us, together 21.7 us per c_fc launch)
+    // A K-step's operands arrive as 4 NS + 4 NSPL one-KiB pieces per wave (8 rows x 128 B each), LDS-DMA through buffer
+    // descriptors: the per-lane part of an address (row within the piece, swizzled 16-byte chunk) is one VGPR per operand and
+    // piece parity, everything else — tile, piece, plane, K-step — a scalar offset, so a piece costs two scalar instructions and
+    // the load (the first version computed a 64-bit VGPR address per piece: ~6 vector instructions each, and the matrix pipe
+    // waited for them: ~540 of the 2950 cycles of a K-step).  Rows past the operand's end are out of the descriptor's range and
+    // arrive as zeros (they are never stored).
     constexpr int NPC = 4 * NS + 4 * NSPL;  // pieces per wave and K-step
-    auto issue_piece = [&](int t, int idx) {
-        char* slot = lds + ((t - t0) & 1) * kStageB;
-        if (idx < 4 * NS) stage_piece<4 * NS>(B, K, n0, N, t * BK, slot, wave, lane, idx);
-        else {
-            const int p = (idx - 4 * NS) >> 2, q = (idx - 4 * NS) & 3;
-            stage_piece<4>(A, kSplit * K, m0, M, p * K + t * BK, slot + kBBytes + p * kTileBytes, wave, lane, q);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (unsigned)((size_t)M * kSplit * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+    unsigned rel_a[2], rel_b[2];
+    {
+        const unsigned l3 = (unsigned)lane >> 3, pos = (unsigned)lane & 7u;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned chunk = pos ^ (((l3 >> 1) + 4u * e) & 7u);
+            rel_a[e] = l3 * (unsigned)(kSplit * K * 2) + chunk * 16u;
+            rel_b[e] = l3 * (unsigned)(K * 2) + chunk * 16u;
         }
+    }
+    // kill: 0, or an offset past every descriptor's end — the piece then fetches nothing and writes zeros (the step behind the
+    // last one: an unconditional piece costs two scalar adds, a tested one a branch between two MFMAs)
+    auto issue_piece = [&](int t, int idx, unsigned kill = 0u) {
+        char* slot = lds + ((t - t0) & 1) * kStageB;
+        if (idx < 4 * NS) {
+            const int piece = wv * (4 * NS) + idx;
+            const unsigned soff = ((unsigned)(n0 + piece * 8) * (unsigned)K + (unsigned)(t * BK)) * 2u + kill;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + piece * 1024), 16, rel_b[idx & 1], soff, 0, 0);
+        } else {
+            const int p = (idx - 4 * NS) >> 2, q = (idx - 4 * NS) & 3, piece = wv * 4 + q;
+            const unsigned soff = ((unsigned)(m0 + piece * 8) * (unsigned)(kSplit * K) + (unsigned)(p * K + t * BK)) * 2u + kill;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + kBBytes + p * kTileBytes + piece * 1024), 16, rel_a[q & 1], soff, 0, 0);
+        }
+    };
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int idx = 0; idx < NPC; ++idx) issue_piece(t, idx);
     };
     if (t0 < nt) issue(t0);
     if (EPI == PF_QKV) {  // the epilogue's argument-block fields, fetched under the first DMA
@@ -282,14 +271,15 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
     for (int t = t0; t < nt; ++t) {
         ZG_PFS(0, __builtin_amdgcn_s_waitcnt(0x0f70));  // vmcnt(0): this wave's pieces of stage t landed
         ZG_PFS(1, __builtin_amdgcn_s_barrier());        // everyone's did, and nobody still reads the other slot
-        // (`more` is tested per piece — a uniform branch between two MFMAs.  Two copies of the body, with and without the pieces,
-        // were measured: the compiler then keeps the accumulators in VGPRs across the loop and moves all 64 to the accumulation
-        // file and back around the MFMAs of every step — 3257 against 2817 cycles per K-step.)
+        // (Two copies of the body, with and without the pieces, were measured too: the compiler then keeps the accumulators in
+        // VGPRs across the loop and moves all 64 to the accumulation file and back around the MFMAs of every step — 3257
+        // against 2817 cycles per K-step.)
 #if defined(ZG_PF_ABL) && (ZG_PF_ABL & 1)
         const bool more = false;  // ablation: no LDS-DMA in the loop (stale operands)
 #else
         const bool more = t + 1 < nt;
 #endif
+        const unsigned kill = more ? 0u : 0xC0000000u;
         const char* cur = lds + ((t - t0) & 1) * kStageB;
         // 12 groups (16-k slice kk, plane p = 2, 1, 0: smallest plane first) of 2 NJ MFMAs.  The fragments of group g + 1 are
         // read IN FRONT of group g's MFMAs (two register sets, sched barriers pin the order): with one wave per SIMD nothing
@@ -357,8 +347,12 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
                     }
 #endif
                 } else {
-                    const int piece = kk * (MS - RSLOT) + (m - RSLOT);
-                    if (piece < NPC && more) issue_piece(t + 1, piece);
+                    // pieces spread evenly over the free MFMAs of the first three slices (packed into the first ones the four waves
+                    // asked the CU's one global -> LDS path for a whole 64-KiB stage within a third of the step)
+                    constexpr int F = MS - RSLOT, SPAN = (NPC <= 3 * F) ? 3 * F : 4 * F;
+                    const int f = kk * F + (m - RSLOT);
+                    const int k = (f * NPC + SPAN - 1) / SPAN;  // the piece whose slot floor(k SPAN / NPC) could be f
+                    if (f < SPAN && k < NPC && (k * SPAN) / NPC == f) issue_piece(t + 1, k, kill);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -367,7 +361,8 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
 #ifdef ZG_PF_STAMPS
     const unsigned long long pfs_t1 = __builtin_readcyclecounter();
 #endif
-    __builtin_amdgcn_s_barrier();  // ring no longer read: it becomes the store staging area
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the (empty) pieces of the step behind the last one have written their zeros
+    __builtin_amdgcn_s_barrier();        // ring no longer read: it becomes the store staging area
 
     // epilogue: each 64 x 64 fp32 strip of the wave goes through LDS so that global accesses are 16-B row segments
     float* wtile = reinterpret_cast<float*>(lds + wave * (64 * 64 * 4));
