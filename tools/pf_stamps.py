@@ -21,7 +21,7 @@ for _ in range(3):
     m.prefill(toks, compute_logits=False)
 out = (C.c_ulonglong * 32)()
 assert raw.zg_debug_prefill_stamps(out, 32) == 0
-ks, wait, bar, loop, epi, e = [int(out[i]) for i in range(6)]
-print(f"EPI {e}: {ks} K-steps, K loop {loop} cycles = {loop / max(ks, 1):.0f} per K-step (48 MFMAs = 1536), of which vmcnt(0) waits {wait} "
+ks, wait, bar, loop, epi, e, pro = [int(out[i]) for i in range(7)]
+print(f"EPI {e}: entry to loop {pro} cycles; {ks} K-steps, K loop {loop} cycles = {loop / max(ks, 1):.0f} per K-step (48 MFMAs = 1536), of which vmcnt(0) waits {wait} "
       f"({wait / max(ks, 1):.0f} per step), barrier {bar} ({bar / max(ks, 1):.0f} per step); barrier + epilogue {epi}")
 m.close()

@@ -177,6 +177,9 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
     // (2^-17 relative per activation, ~2e-5 of the logit scale end to end: inside north_star's 1e-3, outside the
     // strict near-zero floor of the tests; 2/3 of the matrix work)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
+#ifdef ZG_PF_STAMPS
+    const unsigned long long pfs_entry = __builtin_readcyclecounter();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
@@ -411,6 +414,7 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
         g_pf_stamps[3] = pfs_t1 - pfs_t0;                       // the K loop
         g_pf_stamps[4] = __builtin_readcyclecounter() - pfs_t1;  // barrier + epilogue
         g_pf_stamps[5] = (unsigned long long)EPI;
+        g_pf_stamps[6] = pfs_t0 - pfs_entry;  // entry .. first K-step (descriptors, zeroed accumulators, first stage issued)
     }
 #endif
 }
