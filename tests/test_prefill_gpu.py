@@ -26,7 +26,7 @@ def make(cfg, seed, **kw):
 
 
 @pytest.mark.parametrize("name,lengths", [("tiny", [1, 2, 5, 31, 32, 33, 64]), ("tiny3", [7, 48]),
-                                          ("nano-char", [3, 127, 128, 129, 256])])
+                                          ("nano-char", [3, 127, 128, 129, 256]), ("xl-slice", [40, 95])])
 def test_prefill_logits_and_cache_match_oracle(zg, name, lengths):
     """logits of position n-1 after prefill(n tokens) == oracle after n GPT.forward calls; then one decode
     step on top of the prefilled caches == the oracle's next step (pins the KV cache contents)."""
