@@ -266,6 +266,14 @@ def other_config(lib, stream, model_name, ppg, gens, seed, kv_b24=False):
         kv_total = sum(kvb * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
         step_bytes_total = wbytes * ctx + kv_total
         table, dom, lm = kernel_table(model, lib, cfg, ppg, 2, kvb)
+        # the whole-prompt pass of this configuration: ctx - 1 tokens per prompt (synchronous calls, host wall clock)
+        ptoks = np.stack([synth.rand_tokens(3000 + seed * 17 + b, ctx - 1, cfg.vocab_size) for b in range(ppg)])
+        for _ in range(2):
+            model.prefill(ptoks, compute_logits=False)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.prefill(ptoks, compute_logits=False)
+        pf_ms = (time.perf_counter() - t0) / 3 * 1e3
         return {
             "workload": f"GPT-2 {model_name} greedy decode, {ppg} prompt(s) on one GPU, 1-token prompts, {ctx} decode steps per prompt",
             "value": round(ppg * (ctx - 1) * gens / wall, 1), "unit": "tokens/s", "generations": gens, "ms_per_generation": round(1e3 * wall / gens, 3),
@@ -278,6 +286,7 @@ def other_config(lib, stream, model_name, ppg, gens, seed, kv_b24=False):
             "dominant_class": {k: dom[k] for k in ("class", "kernel_symbol", "avg_launch_us", "avg_launch_us_layers_walked", "algorithmic_bytes_per_launch",
                                                    "GBps", "frac_of_8TBps", "share_of_token_time")},
             "lm_head": {k: lm[k] for k in ("kernel_symbol", "avg_launch_us", "GBps", "frac_of_8TBps")},
+            "prefill": {"prompt_tokens": ctx - 1, "prompts": ppg, "ms": round(pf_ms, 3), "prompt_tokens_per_s": round(ppg * (ctx - 1) / pf_ms * 1e3, 1)},
             "data": "synthetic (torch.randn on the GPU, bf16-representable)", "first_tokens": [int(t) for t in ids[0, :4]],
         }
     finally:
@@ -441,8 +450,8 @@ def main():
                        "linear_tflops_useful": round(lin_flops / p_ms / 1e9, 1),
                        "vs_token_at_a_time": round((1e3 * elapsed / a.steps) * n_p / ctx / p_ms, 1),
                        "how": "synchronous zg_gpt_prefill calls (host wall clock, 5 repetitions after 3 warm-ups); "
-                              + ("fp32 weights: both GEMM operands as exact bf16 plane triples, six plane products on the "
-                                 "persistent MFMA GEMM" if a.weights_f32 else
+                              + ("fp32 weights: both GEMM operands as exact bf16 plane triples, the six plane products as three "
+                                 "passes of one launch of the 128-row prompt GEMM per Linear" if a.weights_f32 else
                                  "activations split exactly 3-way into bf16 for the MFMA GEMMs") + ", fp32-MFMA causal attention"}
             if not a.weights_f32:  # the two-plane mode (inside north_star's 1e-3, outside the tests' near-zero floor)
                 m2 = gpt.GPT(cfg, batch=ppg, use_graph=False, kv_f16=a.kv_f16, kv_b24=a.kv_b24, prefill_planes=2)
