@@ -845,6 +845,9 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
                         float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv, int nsplit) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
+    // (the operands are addressed through 32-bit buffer descriptors, and an offset of 3 << 30 must lie past their ends)
+    ZG_REQUIRE((size_t)M * kSplit * K * 2 < ((size_t)3 << 30) && (size_t)N * K * 2 < ((size_t)3 << 30), ZG_ERR_UNSUPPORTED,
+               "prefill gemm: operands of %d x %d x %d beyond 3 GiB", M, N, K);
     ZG_REQUIRE(nsplit == 2 || nsplit == kSplit || nsplit == kWeightPlanes, ZG_ERR_ARG, "prefill gemm: %d activation planes", nsplit);
     const PrefillQkv none{};
     switch (epi) {
