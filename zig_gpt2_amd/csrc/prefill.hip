@@ -312,6 +312,10 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
         };
 #pragma unroll
         for (int r = 0; r < RS; ++r) rd_item(0, r, bq[0], aq[0]);  // the step's first slice: in one burst behind the barrier
+        // ... and while those reads are on their way (nothing can be multiplied yet) the first pieces of the next stage
+        constexpr int PRE = NPC >= 12 ? 4 : 2;  // (8 measured: the wait at the next barrier goes, the body takes it back)
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) issue_piece(t + 1, k, kill);
         // One instruction stream per wave, nothing else on its SIMD: whatever the wave issues between two MFMAs runs in the 32
         // cycles the matrix pipe is busy with the first, and whatever it issues in a burst leaves the pipe idle.  Stamps and
         // ablations of the loop (tools/pf_stamps.py, -DZG_PF_ABL) priced the bursts of the first version per K-step of 48 MFMAs
@@ -352,10 +356,10 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
                 } else {
                     // pieces spread evenly over the free MFMAs of the first three slices (packed into the first ones the four waves
                     // asked the CU's one global -> LDS path for a whole 64-KiB stage within a third of the step)
-                    constexpr int F = MS - RSLOT, SPAN = (NPC <= 3 * F) ? 3 * F : 4 * F;
+                    constexpr int F = MS - RSLOT, NREST = NPC - PRE, SPAN = (NREST <= 3 * F) ? 3 * F : 4 * F;
                     const int f = kk * F + (m - RSLOT);
-                    const int k = (f * NPC + SPAN - 1) / SPAN;  // the piece whose slot floor(k SPAN / NPC) could be f
-                    if (f < SPAN && k < NPC && (k * SPAN) / NPC == f) issue_piece(t + 1, k, kill);
+                    const int k = (f * NREST + SPAN - 1) / SPAN;  // the piece whose slot floor(k SPAN / NREST) could be f
+                    if (f < SPAN && k < NREST && (k * SPAN) / NREST == f) issue_piece(t + 1, PRE + k, kill);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
