@@ -45,6 +45,32 @@ def test_prefill_logits_and_cache_match_oracle(zg, name, lengths):
     m.close()
 
 
+@pytest.mark.parametrize("name,batch,lengths,wgs", [("tiny", 1, [5, 33, 64], None), ("tiny", 3, [21, 64], 2), ("tiny3", 2, [48], 3),
+                                                    ("nano-char", 4, [129, 256], None), ("xl-slice", 1, [95], 5), ("medium-slice", 2, [80], None)])
+def test_prefill_linears_on_the_persistent_four_wave_gemm(zg, monkeypatch, name, batch, lengths, wgs):
+    """Large prompts run their Linears on gemm_s4 (three planes in one K loop; slab epilogue + reduce for the residual adds,
+    GELU + split, qkv + cache append).  ZGPT2_PF_S4_TILES=1 sends every shape there: small models, ragged tile edges (M far
+    below 256, N = 1600 = 8.33 tiles), several tiles per workgroup (ZGPT2_GEMM_WGS), K slices.  Same checks as the 128-row
+    path: last-position logits and the decode step on top of the prefilled caches against the oracle."""
+    monkeypatch.setenv("ZGPT2_PF_S4_TILES", "1")
+    if wgs:
+        monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
+    cfg = synth.CONFIGS[name]
+    m, w = make(cfg, 75, batch=batch)
+    for n in lengths:
+        toks = np.stack([synth.rand_tokens(750 + 7 * b + n, min(n + 1, cfg.context_size), cfg.vocab_size) for b in range(batch)])
+        before = zg.zg_debug_gemm_launches()
+        lg = m.prefill(toks[:, :n])
+        assert zg.zg_debug_gemm_launches() - before >= 4 * cfg.n_layer, "the whole-prompt Linears did not run on gemm_s4"
+        nxt = m.forward(n + 1, toks[:, n]) if n < cfg.context_size else None
+        for b in range(batch):
+            lg_ref = oracle.GPT(cfg, w).forced_logits(toks[b], n - 1)
+            assert_model_close(lg_ref[0], lg[b], f"{name} s4 prefill n={n} row {b}")
+            if nxt is not None:
+                assert_model_close(lg_ref[1], nxt[b], f"{name} decode after s4 prefill n={n} row {b}")
+    m.close()
+
+
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_prefill_batched_rows_are_independent(zg, kv_f16):
     cfg = synth.CONFIGS["tiny"]

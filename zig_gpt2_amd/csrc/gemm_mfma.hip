@@ -524,6 +524,7 @@ int launch_p8_bn(const bf16_t* A, const bf16_t* B, const float* bias, void* C, i
 
 static unsigned long long g_gemm_launches = 0;
 unsigned long long gemm_mfma_launch_count() { return g_gemm_launches; }
+void gemm_note_launch() { ++g_gemm_launches; }
 static int g_last_gemm_kernel = 0;  // 0 s4 / p8, 1 ov
 int gemm_debug_stamps(unsigned long long* out, size_t n_words) {
     return g_last_gemm_kernel == 1 ? gemm_ov_stamps(out, n_words) : gemm_s4_stamps(out, n_words);

@@ -21,6 +21,7 @@
 
 #include <type_traits>
 
+#include "prefill_epi.h"
 #include "zg_kernels.h"
 
 namespace zg {
@@ -181,14 +182,24 @@ __device__ __forceinline__ void read_b_all(bf16x8 (&fb)[4][NT], const unsigned (
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[ks][j]) : "v"(b_addr[ks]), "i"(X * P::B_SLOT + j * 4096));
 }
 
-template <int NT, bool GELU, bool OUT_BF16, int ABL>
+// KIND: what a finished tile becomes.
+//   S4_PLAIN    bias (+ GELU), fp32 or bf16 rows of C[M][ldc]                                     (Linear.forward, src/ops.zig:21-46)
+//   S4_PARTIAL  fp32 partial sums of K slice s into slab s of C[slices][M][ldc], no bias: the whole-prompt Linears whose N gives
+//               too few tiles (N = n_embed) slice K over the tile list; prefill.hip's reduce kernels sum the slabs in fixed
+//               order and finish (bias, residual, LayerNorm + plane split)
+//   S4_QKV      bias, fp32 rows of qkv[M][3E] AND the cache append of src/ops.zig:152-157 for the K / V columns
+//   S4_SPLIT3   bias + GELU, then the exact three-term bf16 split as planes C[M][3N] = [hi | mid | lo]  (src/main.zig:79-80 feeding
+//               the next Linear's A operand)
+
+template <int NT, int KIND, bool GELU, bool OUT_BF16, int ABL>
 __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, void* __restrict__ C, int M, int N,
-                                                         unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+                                                         unsigned p0, unsigned p1, unsigned p2, unsigned p3, const PrefillQkv qa) {
     // All 14 dwords of the arguments are preloaded into SGPRs at wave launch (zg_common.h ZG_PIN): the first version passed the
     // plane description and the tile counts behind them and began with a scalar round trip to the kernarg segment — cold for
     // every launch — before its first DMA.  p0 = lda | ldb << 16; p1 = ldc | K-steps per plane << 20 | plane pairs << 28;
-    // p2 = A plane of pair i in bits [2i, 2i + 2) | B planes << 12 | band width << 24; p3 = workgroups | dbg << 10.
+    // p2 = A plane of pair i in bits [2i, 2i + 2) | B planes << 12 | band width << 24; p3 = workgroups | dbg << 10 | K slices << 20.
+    // (qa — the cache description of S4_QKV — lies behind the preloaded dwords: its fields are fetched under the first DMA)
     using P = S4<NT>;
     GemmPlanes pl;
     pl.lda = (int)(p0 & 0xffffu);
@@ -199,7 +210,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     pl.pa_bits = p2 & 0xfffu;
     pl.pb_bits = (p2 >> 12) & 0xfffu;
     const int gw = (int)(p2 >> 24);
-    const int dbg = (int)(p3 >> 10);
+    const int dbg = (int)((p3 >> 10) & 0x3ffu);
+    const int n_sl = KIND == S4_PARTIAL ? (int)(p3 >> 20) : 1;  // K slices: slice s of a tile walks K-steps [s kps, (s + 1) kps) of every plane
     const int tiles_m = (M + 255) >> 8, tiles_n = (N + P::BN - 1) / P::BN;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     const unsigned lds_base = (unsigned)(unsigned long)(lds_ptr_t)lds;
 
     // ---- this workgroup's tiles: XCD x = bid % 8 owns a contiguous range of the banded order
-    const int n_tiles = tiles_m * tiles_n, G = (int)(p3 & 0x3ffu), bid = blockIdx.x;
+    const int tmn = tiles_m * tiles_n, n_tiles = tmn * n_sl, G = (int)(p3 & 0x3ffu), bid = blockIdx.x;
     const int nx = G < 8 ? G : 8;
     const int xcd = bid % nx, loc = bid / nx;
     const int gx = G / nx + (xcd < G % nx ? 1 : 0);
@@ -267,25 +279,33 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     const unsigned b_addr[4] = {b_addr0, b_addr0 ^ 32u, b_addr0 ^ 64u, b_addr0 ^ 96u};
 
     // ---- K-steps walk the plane pairs: step kt = pair * kpp + kk multiplies A plane pa[pair] with B plane pb[pair]
-    const int kpp = pl.kpp;
+    const int kpp = pl.kpp;                                   // K-steps per plane (the plane stride of both operands)
+    const int kps = KIND == S4_PARTIAL ? kpp / n_sl : kpp;    // ... and those one tile walks
     int pi_cur = 0, kk_cur = 0;
-    int tm, tn;
-    tile_of(idx, tiles_m, tiles_n, gw, tm, tn);
-    const unsigned strideA = 256u * lda2, strideB = (unsigned)P::BN * ldb2;
-    unsigned curA = (unsigned)tm * strideA, curB = (unsigned)tn * strideB;
+    int tm, tn, sl = 0;
+    auto locate = [&](int i, int& tm_, int& tn_, int& sl_) {  // the tile list: slice-major, then the banded order
+        if constexpr (KIND == S4_PARTIAL) {
+            sl_ = i / tmn;
+            i -= sl_ * tmn;
+        }
+        tile_of(i, tiles_m, tiles_n, gw, tm_, tn_);
+    };
+    locate(idx, tm, tn, sl);
+    const unsigned strideA = 256u * lda2, strideB = (unsigned)P::BN * ldb2, strideK = (unsigned)kps * 128u;
+    unsigned curA = (unsigned)tm * strideA + (unsigned)sl * strideK, curB = (unsigned)tn * strideB + (unsigned)sl * strideK;
     int m0 = tm * 256, n0 = tn * P::BN;
     constexpr unsigned kOob = 0x80000000u;  // tile base of "no next tile": every lane out of range -> zero fill
     unsigned nxtA = kOob, nxtB = kOob;
-    int nidx = idx + gx, ntm = 0, ntn = 0;
+    int nidx = idx + gx, ntm = 0, ntn = 0, nsl = 0;
     if (nidx < t_end) {
-        tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
-        nxtA = (unsigned)ntm * strideA;
-        nxtB = (unsigned)ntn * strideB;
+        locate(nidx, ntm, ntn, nsl);
+        nxtA = (unsigned)ntm * strideA + (unsigned)nsl * strideK;
+        nxtB = (unsigned)ntn * strideB + (unsigned)nsl * strideK;
     }
-    auto ahead = [&](int d) {  // K-step t + d of the stream (d <= 2 <= kpp); runs on into the next tile
+    auto ahead = [&](int d) {  // K-step t + d of the stream (d <= 2 <= kps); runs on into the next tile
         int kk = kk_cur + d, pi = pi_cur;
-        if (kk >= kpp) {
-            kk -= kpp;
+        if (kk >= kps) {
+            kk -= kps;
             ++pi;
         }
         const bool in_cur = pi < pl.npairs;
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     u32x4 pend[NPEND > 0 ? NPEND : 1];
     unsigned pend_row = 0, no_store_mask = (dbg & 1) ? 0xFFFFFFFFu : 0u;  // byte offset of (row l31 of m-tile 0, wave's column 0)
     int pend_col = 0, pend_n = NPEND;                                       // wave's first column + 8 hh; stores issued so far
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)((size_t)M * ldc * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)((size_t)n_sl * M * ldc * ESZ), 0x00020000);
     auto store_q = [&](auto QT, const u32x4& o, unsigned row0, int col0) {  // store q = (j * 4 + i) * 2 + p of a tile
         constexpr int q = decltype(QT)::value, i = (q / 2) % 4, j = (q / 2) / 4, pp = q % 2;
         const int col = col0 + j * 32 + 16 * pp;
@@ -537,6 +557,56 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                 g_off[k] = (col < N ? (unsigned)(m0 + wr * 128 + row) * (unsigned)(ldc * 2) + (unsigned)col * 2u : 0xFFFFFFFFu) | no_store_mask;
             }
         }
+        if constexpr (KIND == S4_SPLIT3) {
+            // GELU, then the three planes of an m-tile one after the other through the wave's staging image (its LDS accesses
+            // complete in order: plane p + 1 is written behind the reads of plane p without a wait)
+            static_for<4>([&](auto IT) {
+                constexpr int i = decltype(IT)::value;
+                u32x2 w[3][NT][4];
+                static_for<NT>([&](auto JT) {
+                    constexpr int j = decltype(JT)::value;
+                    asm volatile("s_nop 3" ::: "memory");
+                    float av[16];
+                    acc_read16<16 * (i * NT + j)>(av);
+                    f32x2v x[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[k] = gelu2(f32x2v{av[2 * k], av[2 * k + 1]});
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint32_t a[3], b[3];
+                        split3_pk(x[2 * g].x, x[2 * g].y, a[0], a[1], a[2]);
+                        split3_pk(x[2 * g + 1].x, x[2 * g + 1].y, b[0], b[1], b[2]);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) w[p][j][g] = u32x2{a[p], b[p]};
+                    }
+                });
+                static_for<3>([&](auto PT) {
+                    constexpr int p = decltype(PT)::value;
+                    static_for<NT>([&](auto JT) {
+                        constexpr int j = decltype(JT)::value;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned st_w_l = st_w;
+                            const u32x2 pk = w[p][j][g];
+                            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(st_w_l), "v"(pk), "i"(j * 64 + g * 16) : "memory");
+                        }
+                    });
+                    u32x4 o[NCH];
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {
+                        const unsigned st_r_l = st_r[k];
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(o[k]) : "v"(st_r_l) : "memory");
+                    }
+                    static_assert(NCH == 6, "staging read-back written for NT = 3");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]));
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k) {  // plane p of row m: columns [p N, (p + 1) N) of the 3 N-wide row
+                        const unsigned off = g_off[k] == 0xFFFFFFFFu ? g_off[k] : g_off[k] + (unsigned)(i * 32) * (unsigned)(ldc * 2) + (unsigned)(p * N) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b128(o[k], rc, off, 0, ST_AUX);
+                    }
+                });
+            });
+        } else
         static_for<4>([&](auto IT) {
             constexpr int i = decltype(IT)::value;
             static_for<NT>([&](auto JT) {
@@ -576,6 +646,21 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                         const u32x2 pk = {cvt_pk_bf16(x[2 * g].x, x[2 * g].y), cvt_pk_bf16(x[2 * g + 1].x, x[2 * g + 1].y)};
                         const unsigned st_w_l = st_w;  // (a generic lambda does not capture what only an asm operand names)
                         asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(st_w_l), "v"(pk), "i"(j * 64 + g * 16) : "memory");
+                    }
+                } else if constexpr (KIND == S4_PARTIAL || KIND == S4_QKV) {
+                    // whole-prompt Linears (N % 64 == 0): slab rows / qkv rows, write-through (the next kernel reads them from every
+                    // XCD); a row past M would land in the next slab, so it is masked here instead of by the descriptor's end
+                    const int row = m0 + wr * 128 + i * 32 + l31e;
+                    const unsigned rbase = row < M ? (unsigned)(sl * M + row) * (unsigned)(ldc * 4) : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = gcol + 8 * g + 4 * hhe;
+                        const unsigned off = (col < N && rbase != 0xFFFFFFFFu) ? rbase + (unsigned)col * 4u : 0xFFFFFFFFu;
+                        const f32x4v o = {x[2 * g].x, x[2 * g].y, x[2 * g + 1].x, x[2 * g + 1].y};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, ST_AUX);
+                        if constexpr (KIND == S4_QKV) {
+                            if (row < M && col < N) qkv_cache_store(qa, row, col, f32x4{o[0], o[1], o[2], o[3]});
+                        }
                     }
                 } else {
 #pragma unroll
@@ -627,6 +712,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         idx = nidx;
         m0 = ntm * 256;
         n0 = ntn * P::BN;
+        sl = nsl;
         tile_par ^= 1;
         curA = nxtA;
         curB = nxtB;
@@ -634,14 +720,14 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         nxtA = kOob;
         nxtB = kOob;
         if (nidx < t_end) {
-            tile_of(nidx, tiles_m, tiles_n, gw, ntm, ntn);
-            nxtA = (unsigned)ntm * strideA;
-            nxtB = (unsigned)ntn * strideB;
+            locate(nidx, ntm, ntn, nsl);
+            nxtA = (unsigned)ntm * strideA + (unsigned)nsl * strideK;
+            nxtB = (unsigned)ntn * strideB + (unsigned)nsl * strideK;
             fetch_bias(ntn * P::BN, tile_par ^ 1);  // a whole tile ahead of its use (its buffer was last read before this tile began)
         }
     };
     auto advance = [&]() {  // K-step t -> t + 1; true at the end of the tile
-        if (++kk_cur == kpp) {
+        if (++kk_cur == kps) {
             kk_cur = 0;
             ++pi_cur;
         }
@@ -669,6 +755,9 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         for (int i = 0; i < 4; ++i) dma_a(0, 1, i, s0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_a(1, 0, i, s1);
+        if constexpr (KIND == S4_QKV) {  // the epilogue's argument-block fields, fetched under the first DMA
+            ZG_PIN(qa.P); ZG_PIN(qa.E); ZG_PIN(qa.H); ZG_PIN(qa.ctx); ZG_PIN(qa.kv_mode); ZG_PIN(qa.kv_lo); ZG_PIN(qa.k_cache); ZG_PIN(qa.v_cache);
+        }
         if constexpr (P::PB == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // B and A half 0 of K-step 0 are in
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         bar();
@@ -713,16 +802,17 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     }
 }
 
-template <int NT, bool GELU, bool OUT_BF16, int ABL>
-int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, hipStream_t s) {
+template <int NT, int KIND, bool GELU, bool OUT_BF16, int ABL>
+int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, int n_sl,
+                  const PrefillQkv& qa, hipStream_t s) {
     using P = S4<NT>;
     static bool raised = false;
     if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, GELU, OUT_BF16, ABL>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, ABL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
         raised = true;
     }
-    const int tiles_m = (M + 255) / 256, tiles_n = (N + P::BN - 1) / P::BN, n_tiles = tiles_m * tiles_n;
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + P::BN - 1) / P::BN, n_tiles = tiles_m * tiles_n * n_sl;
     const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
     int gw = gw_env > 0 ? gw_env : 8;
     if (gw > tiles_n) gw = tiles_n;
@@ -730,40 +820,41 @@ int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, 
     const int cus = cus_env > 0 ? cus_env : 256;
     const int grid = n_tiles < cus ? n_tiles : cus;
     const unsigned dbg = (unsigned)(getenv("ZGPT2_GEMM_DBG") ? atoi(getenv("ZGPT2_GEMM_DBG")) : 0);
-    ZG_REQUIRE(gemm_s4_args_ok(pl, ldc) && gw < 256 && grid < 1024 && dbg < (1u << 22), ZG_ERR_UNSUPPORTED,
+    ZG_REQUIRE(gemm_s4_args_ok(pl, ldc) && gw < 256 && grid < 1024 && dbg < (1u << 10) && n_sl >= 1 && n_sl < 256, ZG_ERR_UNSUPPORTED,
                "gemm: lda %d / ldb %d / ldc %d / K beyond the packed kernel arguments", pl.lda, pl.ldb, ldc);
     unsigned pa2 = 0, pb2 = 0;
     for (int i = 0; i < pl.npairs; ++i) {
         pa2 |= ((pl.pa_bits >> (4 * i)) & 3u) << (2 * i);
         pb2 |= ((pl.pb_bits >> (4 * i)) & 3u) << (2 * i);
     }
-    hipLaunchKernelGGL((gemm_s4_kernel<NT, GELU, OUT_BF16, ABL>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
+    hipLaunchKernelGGL((gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, ABL>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
                        (unsigned)pl.lda | ((unsigned)pl.ldb << 16), (unsigned)ldc | ((unsigned)pl.kpp << 20) | ((unsigned)pl.npairs << 28),
-                       pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10));
+                       pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10) | ((unsigned)n_sl << 20), qa);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 template <int NT, bool GELU, bool OUT_BF16>
 int launch_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, hipStream_t s) {
+    const PrefillQkv none{};
     if constexpr (NT == 3 && GELU && OUT_BF16) {  // the benchmarked instantiation carries the ablation builds
         const int abl = getenv("ZGPT2_S4_ABL") ? atoi(getenv("ZGPT2_S4_ABL")) : 0;
         switch (abl) {
-            case 1: return launch_s4_abl<NT, GELU, OUT_BF16, 1>(A, B, bias, C, M, N, pl, ldc, s);
-            case 2: return launch_s4_abl<NT, GELU, OUT_BF16, 2>(A, B, bias, C, M, N, pl, ldc, s);
-            case 3: return launch_s4_abl<NT, GELU, OUT_BF16, 3>(A, B, bias, C, M, N, pl, ldc, s);
-            case 4: return launch_s4_abl<NT, GELU, OUT_BF16, 4>(A, B, bias, C, M, N, pl, ldc, s);
-            case 7: return launch_s4_abl<NT, GELU, OUT_BF16, 7>(A, B, bias, C, M, N, pl, ldc, s);
-            case 8: return launch_s4_abl<NT, GELU, OUT_BF16, 8>(A, B, bias, C, M, N, pl, ldc, s);
-            case 9: return launch_s4_abl<NT, GELU, OUT_BF16, 9>(A, B, bias, C, M, N, pl, ldc, s);
-            case 11: return launch_s4_abl<NT, GELU, OUT_BF16, 11>(A, B, bias, C, M, N, pl, ldc, s);
-            case 16: return launch_s4_abl<NT, GELU, OUT_BF16, 16>(A, B, bias, C, M, N, pl, ldc, s);
-            case 32: return launch_s4_abl<NT, GELU, OUT_BF16, 32>(A, B, bias, C, M, N, pl, ldc, s);
-            case 48: return launch_s4_abl<NT, GELU, OUT_BF16, 48>(A, B, bias, C, M, N, pl, ldc, s);
+            case 1: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 1>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 2: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 2>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 3: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 3>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 4: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 4>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 7: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 7>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 8: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 8>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 9: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 9>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 11: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 11>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 16: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 16>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 32: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 32>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+            case 48: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 48>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
             default: break;
         }
     }
-    return launch_s4_abl<NT, GELU, OUT_BF16, 0>(A, B, bias, C, M, N, pl, ldc, s);
+    return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 0>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
 }
 
 template <int NT>
@@ -794,6 +885,41 @@ int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C,
                    bool gelu, bool out_bf16, int bn, hipStream_t s) {
     (void)bn;  // 192-wide tiles only: 256 x 256 needs all 256 accumulator registers plus 128 of B fragments
     return launch_s4_nt<3>(A, B, bias, C, M, N, pl, ldc, gelu, out_bf16, s);
+}
+
+// The whole-prompt Linears on the same kernel (prefill.hip decides when): A = the activation planes [M][nplanes K] (hi | mid | lo),
+// W = the bf16 weight [N][K]; the planes are plane pairs of ONE K loop, smallest first — a tile's accumulators see 3 K / 64
+// K-steps between two epilogues.  kind: S4_PARTIAL (C = fp32 slabs [n_slices][M][N], bias must be null), S4_QKV (C = qkv [M][N]
+// fp32 + cache append), S4_SPLIT3 (C = bf16 planes [M][3 N] of gelu(...)).
+int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int nplanes, int kind, int n_slices,
+                           const PrefillQkv* qkv, hipStream_t s) {
+    ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0 && K >= 128 && (nplanes == 2 || nplanes == 3), ZG_ERR_UNSUPPORTED, "s4 prefill gemm: M=%d N=%d K=%d planes=%d", M, N, K, nplanes);
+    GemmPlanes pl{};
+    pl.lda = kSplit * K;  // the plane buffer always holds three planes per row; nplanes = 2 multiplies hi + mid only
+    pl.ldb = K;
+    pl.kpp = K / 64;
+    pl.npairs = nplanes;
+    pl.pa_bits = nplanes == 3 ? 0x012u : 0x01u;  // pair 0 = the smallest plane
+    pl.pb_bits = 0;
+    const int ldc = kind == S4_SPLIT3 ? kSplit * N : N;
+    const size_t out_bytes = (size_t)(kind == S4_PARTIAL ? n_slices : 1) * M * ldc * (kind == S4_SPLIT3 ? 2 : 4);
+    ZG_REQUIRE(out_bytes < ((size_t)1 << 32) && (size_t)M * pl.lda * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 31), ZG_ERR_SHAPE,
+               "s4 prefill gemm: operands of %d x %d x %d beyond the 32-bit buffer descriptors", M, N, K);
+    ZG_REQUIRE(n_slices >= 1 && pl.kpp % n_slices == 0 && pl.kpp / n_slices >= 2, ZG_ERR_ARG, "s4 prefill gemm: %d K slices of %d K-steps", n_slices, pl.kpp);
+    const PrefillQkv none{};
+    gemm_note_launch();
+    switch (kind) {
+        case S4_PARTIAL:
+            ZG_REQUIRE(bias == nullptr, ZG_ERR_ARG, "s4 prefill gemm: partial slabs carry no bias");
+            return launch_s4_abl<3, S4_PARTIAL, false, false, 0>(A, W, nullptr, C, M, N, pl, ldc, n_slices, none, s);
+        case S4_QKV:
+            ZG_REQUIRE(qkv && N == 3 * qkv->E && n_slices == 1, ZG_ERR_ARG, "s4 prefill gemm: S4_QKV needs the cache description");
+            return launch_s4_abl<3, S4_QKV, false, false, 0>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
+        case S4_SPLIT3:
+            ZG_REQUIRE(n_slices == 1, ZG_ERR_ARG, "s4 prefill gemm: S4_SPLIT3 is not sliced");
+            return launch_s4_abl<3, S4_SPLIT3, true, true, 0>(A, W, bias, C, M, N, pl, ldc, 1, none, s);
+    }
+    ZG_REQUIRE(false, ZG_ERR_ARG, "s4 prefill gemm: kind %d", kind);
 }
 
 }  // namespace zg

@@ -21,6 +21,7 @@
 //                      statistic lives in one lane                           (src/ops.zig:249-307)
 #include <stdlib.h>
 
+#include "prefill_epi.h"
 #include "zg_kernels.h"
 
 namespace zg {
@@ -102,29 +103,6 @@ __global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__
         o.z = (v.z - mean) / sd * gg.z + bb.z;
         o.w = (v.w - mean) / sd * gg.w + bb.w;
         store_split4(hi + e, E, o);
-    }
-}
-
-// Cache append for four consecutive columns [n, n + 4) >= E of qkv row m (PF_QKV epilogue).
-__device__ __forceinline__ void qkv_cache_store(const PrefillQkv& q, int m, int n, f32x4 v) {
-    if (n < q.E) return;
-    const int which = n >= 2 * q.E;
-    const int e = n - (which ? 2 * q.E : q.E);
-    const int b = m / q.P, t = m - b * q.P;
-    const size_t off = (((size_t)b * q.H + (e >> 6)) * q.ctx + t) * 64 + (e & 63);
-    void* cache = which ? q.v_cache : q.k_cache;
-    if (q.kv_mode == 2) {  // four elements: 8 bytes of the bf16 plane, 4 of the byte plane
-        const uint32_t r0 = b24_round(v.x), r1 = b24_round(v.y), r2 = b24_round(v.z), r3 = b24_round(v.w);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(cache) + off) = u32x2{(r0 >> 8) | ((r1 >> 8) << 16), (r2 >> 8) | ((r3 >> 8) << 16)};
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cache) + q.kv_lo + off) =
-            (r0 & 0xffu) | ((r1 & 0xffu) << 8) | ((r2 & 0xffu) << 16) | (r3 << 24);
-    } else if (q.kv_mode) {
-        _Float16* d = reinterpret_cast<_Float16*>(cache) + off;
-        const float lim = 65504.0f;  // saturate: an inf in the cache would poison masked positions (0 * inf)
-        d[0] = (_Float16)fminf(fmaxf(v.x, -lim), lim); d[1] = (_Float16)fminf(fmaxf(v.y, -lim), lim);
-        d[2] = (_Float16)fminf(fmaxf(v.z, -lim), lim); d[3] = (_Float16)fminf(fmaxf(v.w, -lim), lim);
-    } else {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(cache) + off) = v;
     }
 }
 
@@ -846,9 +824,48 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
     return ZG_OK;
 }
 
+// Large prompts (several sequences): the Linears run on the persistent four-wave kernel of gemm_s4.hip with the activation
+// planes as plane pairs of ONE K loop (K_eff = 3 K between two epilogues) once its 256 x 192 tiles fill most of the chip; the
+// N = n_embed Linears (residual adds) get there by slicing K over the tile list, their partial slabs summed by the reduce
+// kernels above in fixed order (which also apply bias, residual and the LayerNorm + split that follows).  Returns the slice
+// count, 0 = the 128-row kernels of this file take the launch.
+static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws) {
+    const int min_tiles = getenv("ZGPT2_PF_S4_TILES") ? atoi(getenv("ZGPT2_PF_S4_TILES")) : (1 << 30);  // (off until its epilogues beat the 128-row kernels: profiles/round5 notes)
+    const int kpp = K / 64;
+    if (K % 64 != 0 || kpp < 2 || kSplit * K >= 65536) return 0;
+    const long tiles = (long)((M + 255) / 256) * ((N + 191) / 192);
+    if (epi != PF_RESID) return tiles >= min_tiles ? 1 : 0;
+    if (!have_ws) return 0;
+    for (int n_sl = 1; n_sl <= kpp / 2; ++n_sl) {
+        if (kpp % n_sl != 0 || (size_t)n_sl * M * N > ws_floats) continue;
+        if (tiles * n_sl >= min_tiles) return n_sl;
+    }
+    return 0;
+}
+
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
                         float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv, int nsplit) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
+    if (nsplit != kWeightPlanes) {
+        const int n_sl = s4_route(M, N, K, epi, ws_floats, ws != nullptr);
+        if (n_sl > 0 && epi == PF_RESID && ldc == N) {
+            ZG_TRY(launch_gemm_s4_prefill(A, B, nullptr, ws, M, N, K, nsplit, S4_PARTIAL, n_sl, nullptr, s));
+            if (ln && N <= 2048) {
+                hipLaunchKernelGGL(prefill_reduce_resid_ln_kernel, dim3(M), dim3(256), 0, s, ws, n_sl, bias, reinterpret_cast<float*>(C), M, N, ln->g,
+                                   ln->b, ln->eps, ln->out);
+                ZG_HIP(hipGetLastError());
+                return ZG_OK;
+            }
+            const size_t n = (size_t)M * (N / 4);
+            hipLaunchKernelGGL((prefill_reduce_kernel<PF_RESID>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n_sl, bias, C, M, N, ldc,
+                               PrefillQkv{});
+            ZG_HIP(hipGetLastError());
+            if (ln) return launch_ln_split(reinterpret_cast<const float*>(C), M, N, ln->g, ln->b, ln->eps, ln->out, s);
+            return ZG_OK;
+        }
+        if (n_sl == 1 && epi == PF_GELU_SPLIT) return launch_gemm_s4_prefill(A, B, bias, C, M, N, K, nsplit, S4_SPLIT3, 1, nullptr, s);
+        if (n_sl == 1 && epi == PF_QKV && qkv && ldc == N) return launch_gemm_s4_prefill(A, B, bias, C, M, N, K, nsplit, S4_QKV, 1, qkv, s);
+    }
     // (the operands are addressed through 32-bit buffer descriptors, and an offset of 3 << 30 must lie past their ends)
     ZG_REQUIRE((size_t)M * kSplit * K * 2 < ((size_t)3 << 30) && (size_t)N * K * 2 < ((size_t)3 << 30), ZG_ERR_UNSUPPORTED,
                "prefill gemm: operands of %d x %d x %d beyond 3 GiB", M, N, K);

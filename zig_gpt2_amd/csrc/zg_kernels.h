@@ -189,6 +189,11 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
 int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc,
                    bool gelu, bool out_bf16, int bn, hipStream_t s);  // gemm_s4.hip
 bool gemm_s4_args_ok(const GemmPlanes& pl, int ldc);            // the bounds of gemm_s4_kernel's packed arguments
+// ... and its epilogue kinds for the whole-prompt Linears (gemm_s4.hip; PrefillQkv below)
+enum { S4_PLAIN = 0, S4_PARTIAL = 1, S4_QKV = 2, S4_SPLIT3 = 3 };
+struct PrefillQkv;
+int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int nplanes, int kind, int n_slices,
+                           const PrefillQkv* qkv, hipStream_t s);
 int gemm_s4_stamps(unsigned long long* out, size_t n_words);  // diagnostic (ZGPT2_GEMM_DBG bit 256)
 // bf16 result, 192-wide tiles, the epilogue of a tile under the next tile's main loop (gemm_ov.hip)
 bool gemm_ov_args_ok(int M, const GemmPlanes& pl, int ldc);
@@ -196,7 +201,8 @@ int launch_gemm_ov(const bf16_t* A, const bf16_t* B, const float* bias, void* C,
                    hipStream_t s);
 int gemm_ov_stamps(unsigned long long* out, size_t n_words);
 int gemm_debug_stamps(unsigned long long* out, size_t n_words);  // of the kernel generation launched last
-unsigned long long gemm_mfma_launch_count();  // launches of the MFMA GEMM so far (tests assert the path taken)
+unsigned long long gemm_mfma_launch_count();  // launches of the persistent MFMA GEMMs so far (tests assert the path taken)
+void gemm_note_launch();
 
 // ------------------------------------------------------------------------------------ prefill (prefill.hip)
 // Whole-prompt forward.  Activations feeding a GEMM are fp32 split exactly into kSplit bf16 terms,
