@@ -192,6 +192,21 @@ int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len);
 
 /* The weight region of the arena (for an RCCL broadcast to the other GPUs of a node). */
 int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes);
+/* Multi-GPU (no reference counterpart — the reference is single-device): prompts are independent units, sharded
+ * over ONE PROCESS PER GPU; the weights are replicated by one RCCL broadcast over xGMI, nothing is exchanged while tokens are
+ * generated.  The host program (src/main.zig's role) starts one process per GPU; rank 0 makes the id, hands its 128 bytes to
+ * the other ranks by any means (file, pipe, environment), every rank calls zg_init(its device) and zg_dist_init; rank 0 loads
+ * the weights (zg_gpt_load_*), every rank calls zg_gpt_broadcast_weights on its handle of the same config and flags, then
+ * generates its own prompts.  zg_dist_allgather collects equal-sized device buffers (the ranks' token matrices) in rank
+ * order.  RCCL is bound at run time: on a box without librccl.so these return ZG_ERR_UNSUPPORTED, everything else works. */
+#define ZG_DIST_ID_BYTES 128
+int zg_dist_unique_id(void* id_out, size_t id_bytes);
+int zg_dist_init(const void* id, size_t id_bytes, int rank, int world_size);
+int zg_dist_world(int* rank, int* world_size); /* world_size 0: no communicator */
+int zg_gpt_broadcast_weights(zg_gpt* g, int root, float* ms_out_or_null);
+int zg_dist_allgather(const void* send_device, void* recv_device, size_t bytes_per_rank);
+int zg_dist_finalize(void);
+
 /* Bytes one decode step must read at sequence length T: weights + KV. */
 int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* kv_bytes);
 

@@ -62,6 +62,12 @@ SIGNATURES = {
     "zg_gpt_load_block_tensor": (C.c_int, [vp, sz, C.c_int, vp, sz]),
     "zg_gpt_load_tensor": (C.c_int, [vp, C.c_int, vp, sz]),
     "zg_gpt_weight_arena": (C.c_int, [vp, C.POINTER(vp), szp]),
+    "zg_dist_unique_id": (C.c_int, [vp, sz]),
+    "zg_dist_init": (C.c_int, [vp, sz, C.c_int, C.c_int]),
+    "zg_dist_world": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "zg_gpt_broadcast_weights": (C.c_int, [vp, C.c_int, f32p]),
+    "zg_dist_allgather": (C.c_int, [vp, vp, sz]),
+    "zg_dist_finalize": (C.c_int, []),
     "zg_gpt_step_bytes": (C.c_int, [vp, sz, szp, szp]),
     "zg_gpt_forward": (C.c_int, [vp, sz, vp, sz, C.c_int, vp, sz]),
     "zg_gpt_prefill": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, sz]),

@@ -592,7 +592,8 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_attn_p : (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
                                    g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
-        ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
+        if (getenv("ZGPT2_PF_ATTN_OLD")) ZG_TRY(launch_attn_prefill_f32(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
+        else ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, g->pf_ws, g->pf_ws_floats, s));
         const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_proj_p : (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
                                    g->pf_ws_floats, &ln2, s, nullptr, np));
@@ -1140,6 +1141,33 @@ int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes) {
     g->ln_folded = false;
     *device_ptr = g->arena;
     *bytes = g->weight_region_bytes;
+    return ZG_OK;
+}
+
+// load_gpt (src/main.zig:304-314) on ONE GPU of the node, then this: the weight region goes to every other rank's arena in one
+// RCCL broadcast on the library's stream (dist.hip).  ms_out (optional): device time of the broadcast.
+int zg_gpt_broadcast_weights(zg_gpt* g, int root, float* ms_out) {
+    ZG_TRY(require_init());
+    void* p = nullptr;
+    size_t n = 0;
+    ZG_TRY(zg_gpt_weight_arena(g, &p, &n));  // (sender: folded vectors valid; receiver: re-fold at the next forward)
+    hipStream_t s = ctx().stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms_out) {
+        ZG_HIP(hipEventCreate(&e0));
+        ZG_HIP(hipEventCreate(&e1));
+        ZG_HIP(hipEventRecord(e0, s));
+    }
+    const int st = zg::dist_broadcast(p, n, root, s);
+    if (ms_out && st == ZG_OK) ZG_HIP(hipEventRecord(e1, s));
+    const hipError_t he = hipStreamSynchronize(s);
+    if (ms_out) {
+        if (st == ZG_OK && he == hipSuccess) (void)hipEventElapsedTime(ms_out, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    ZG_TRY(st);
+    ZG_HIP(he);
     return ZG_OK;
 }
 

@@ -1,0 +1,336 @@
+// attn_prefill.hip — causal scaled_dot_product_attention for all n prompt positions at once (src/ops.zig:249-307: per head
+// two sgemm calls and a softmax per query row; the reference runs it once per token, src/main.zig:331-334), on the bf16
+// matrix cores at fp32 accuracy.
+//
+// Numerics.  q, k, v arrive as fp32 (the c_attn rows).  Every operand of a matrix product is the EXACT three-term bf16 split
+// x = hi + mid + lo (zg_common.h split3_pk), and a product a . b is the six plane products a_i b_j with i + j <= 2 — what is
+// dropped is below 2^-24 of the leading term, every bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32: the
+// result is fp32-sgemm grade, as the fp32-weight Linears of prefill.hip.  The probabilities are split the same way after the
+// softmax.  16 x the matrix rate of v_mfma_f32_32x32x2_f32 for 6 x the products.
+//
+// Structure.  A workgroup = four waves = four consecutive 32-query blocks of one head (128 queries) against a range of 32-key
+// tiles; the K / V tiles are shared: the four waves fetch a tile as fp32 (a quarter each, coalesced 256-byte rows), split it
+// once and write the planes into LDS — K as [key][64] rows with the 16-byte chunks XOR-swizzled for ds_read_b128 fragment
+// reads, V as four [32 keys][16 d] sub-tiles read back TRANSPOSED by ds_read_b64_tr_b16 (the MFMA wants 8 consecutive keys
+// per lane; tools/microbench/tr_read_probe.hip pins the lane map) — double buffered, one barrier per tile, the next tile's
+// global loads in flight under the current tile's products.  Everything is computed transposed (S^T = K Q^T, O^T = V^T P^T):
+// the query is the lane, so every per-query statistic is one register of one lane and P needs no transpose between the two
+// products (the k index of an MFMA step only has to agree between its operands: the keys a lane holds after S^T are the keys
+// its P fragment multiplies).  Long rows of few sequences are cut into key ranges over several workgroups whose (m, l, O)
+// partials a small kernel merges (one prompt of 1023 tokens would otherwise be 96 workgroups of up to 32 tiles).
+#include "zg_kernels.h"
+
+namespace zg {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int kKPlane = 32 * 128;        // one K plane of a tile: [32 keys][64 d] bf16
+constexpr int kVBlock = 32 * 32 + 128;   // one 16-d block of a V plane: [32 keys][16 d] bf16, + 128 B: the two blocks a half-wave reads
+                                         // in one ds_read_b64_tr_b16 then lie 288 dwords apart — the two halves of the 64 banks
+constexpr int kVPlane = 4 * kVBlock;
+constexpr int kVOff = 3 * kKPlane;
+constexpr int kStage = 3 * kKPlane + 3 * kVPlane;  // 26112 B
+constexpr int kLds = 2 * kStage;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kDefer = 8.0f;  // log2 units
+
+// A query's 32 scores of a tile sit in two lanes (l and l ^ 32, 16 keys each): v_permlane32_swap hands every lane both halves'
+// values (vdst = {lower half's, lower half's}, src0 = {upper half's, upper half's}) — no LDS crossbar, no select
+__device__ __forceinline__ float both_halves_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float both_halves_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return __builtin_bit_cast(bf16x8, u32x4{a, b, c, d}); }
+
+__device__ __forceinline__ void store_split4(bf16_t* dst, size_t plane, f32x4 v) {
+    uint32_t a[3], b[3];
+    split3_pk(v.x, v.y, a[0], a[1], a[2]);
+    split3_pk(v.z, v.w, b[0], b[1], b[2]);
+#pragma unroll
+    for (int p = 0; p < kSplit; ++p) *reinterpret_cast<u32x2*>(dst + p * plane) = u32x2{a[p], b[p]};
+}
+
+// key tiles a group of four query blocks needs, and the key ranges (splits) it is cut into
+__host__ __device__ inline int group_tiles(int g, int nqb) { return 4 * g + 4 < nqb ? 4 * g + 4 : nqb; }
+__host__ __device__ inline int group_splits(int g, int nqb, int nts) { return (group_tiles(g, nqb) + nts - 1) / nts; }
+
+// geo = key tiles per split | most splits of a group << 8 | query groups << 16.  part: [B][H][P][max splits][66] (O^T[64], m, l).
+__global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ part,
+                                                                 int P, int E, unsigned geo) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hl = lane >> 5;
+    const int nts = (int)(geo & 0xffu), max_s = (int)((geo >> 8) & 0xffu), ng = (int)(geo >> 16);
+    // grid (H, B, groups x splits): the dispatcher hands out workgroups in linear order, x fastest — the longest groups of EVERY
+    // (sequence, head) first, the short ones fill the tail (with the groups innermost the last sequence's 32-tile group started
+    // when the rest of the chip was nearly done: 1.0 waves per SIMD on average instead of 2)
+    const int xg = (int)blockIdx.z / max_s, s = (int)blockIdx.z - xg * max_s, g = ng - 1 - xg;
+    const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+    const int nqb = (P + 31) >> 5;
+    const int kt0 = s * nts, kt1 = min((s + 1) * nts, group_tiles(g, nqb));
+    if (kt0 >= kt1) return;
+    const int qb = 4 * g + wave, tq = qb * 32 + l31;
+    const bool active = qb < nqb;
+    const size_t row0 = (size_t)b * P;
+    const int ld = 3 * E;
+
+    // Q^T fragments (B operand of S^T = K Q^T): lane = query, 8 consecutive d per 16-d slice.  Scaled by log2(e) / sqrt(64) before the
+    // split (one fp32 rounding, as the reference's own alpha of sgemm, ops.zig:275) so that the softmax runs on bare v_exp_f32.
+    bf16x8 qf[3][4];
+    {
+        const float sc = 0.125f * kLog2e;
+        const float* qp = qkv + (row0 + min(tq, P - 1)) * ld + h * 64 + hl * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * ks), c = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+            uint32_t w[4][3];
+            split3_pk(a.x * sc, a.y * sc, w[0][0], w[0][1], w[0][2]);
+            split3_pk(a.z * sc, a.w * sc, w[1][0], w[1][1], w[1][2]);
+            split3_pk(c.x * sc, c.y * sc, w[2][0], w[2][1], w[2][2]);
+            split3_pk(c.z * sc, c.w * sc, w[3][0], w[3][1], w[3][2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) qf[p][ks] = frag(w[0][p], w[1][p], w[2][p], w[3][p]);
+        }
+    }
+
+    // staging: wave w fetches keys 8 w .. 8 w + 7 of a tile.  K: 16 lanes x 16 B = one 256-byte head row per key (its LDS row is 128
+    // contiguous bytes: 32 banks).  V: a 16-lane group takes ONE 16-d block of four keys, the 128 contiguous bytes that block is in
+    // LDS (with K's map the four blocks of a row, 288 dwords apart, met on the same banks: a third of all LDS cycles were conflicts)
+    const int skey = wave * 8 + (lane >> 4), sd0 = (lane & 15) * 4;
+    const int vkey = wave * 8 + ((lane & 15) >> 2), vd0 = 16 * (lane >> 4) + 4 * (lane & 3);
+    auto load_tile = [&](int kt, f32x4(&kr)[2], f32x4(&vr)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            kr[j] = *reinterpret_cast<const f32x4*>(qkv + (row0 + min(kt * 32 + skey + 4 * j, P - 1)) * ld + h * 64 + sd0 + E);
+            vr[j] = *reinterpret_cast<const f32x4*>(qkv + (row0 + min(kt * 32 + vkey + 4 * j, P - 1)) * ld + h * 64 + vd0 + 2 * E);
+        }
+    };
+    auto store_tile = [&](int stage, const f32x4(&kr)[2], const f32x4(&vr)[2]) {
+        char* st = lds + stage * kStage;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = skey + 4 * j;
+            const int kaddr = key * 128 + (((sd0 >> 3) ^ ((key >> 1) & 7)) << 4) + ((sd0 >> 2) & 1) * 8;
+            const int vaddr = kVOff + (vd0 >> 4) * kVBlock + (vkey + 4 * j) * 32 + (vd0 & 15) * 2;
+            uint32_t a[3], c[3];
+            split3_pk(kr[j].x, kr[j].y, a[0], a[1], a[2]);
+            split3_pk(kr[j].z, kr[j].w, c[0], c[1], c[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(st + p * kKPlane + kaddr) = u32x2{a[p], c[p]};
+            split3_pk(vr[j].x, vr[j].y, a[0], a[1], a[2]);
+            split3_pk(vr[j].z, vr[j].w, c[0], c[1], c[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(st + p * kVPlane + vaddr) = u32x2{a[p], c[p]};
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
+    float mrun = -INFINITY, lrun = 0.0f;  // running maximum (in log2 units) and sum of this lane's query
+
+    // fragment addresses: K rows by key = l31; V blocks by the 16-lane group (d block) and the lane's place in the 4 x 16 read
+    const int koff = l31 * 128, kswz = (l31 >> 1) & 7;
+    const int voff = kVOff + ((lane >> 4) & 1) * kVBlock + (4 * hl + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+
+    f32x4 kr[2], vr[2];
+    load_tile(kt0, kr, vr);
+    store_tile(0, kr, vr);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int stg = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile(kt + 1, kr, vr);
+        if (active && kt <= qb) {
+            const char* kp = lds + stg * kStage;
+            // ---- S^T = K Q^T over the six plane pairs, smallest terms first
+            bf16x8 kf[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[p][ks] = *reinterpret_cast<const bf16x8*>(kp + p * kKPlane + koff + (((2 * ks + hl) ^ kswz) << 4));
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+            constexpr int PK[6] = {2, 0, 1, 1, 0, 0}, PQ[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t]][ks], qf[PQ[t]][ks], sc, 0, 0, 0);
+            // sc[r] = log2(e) / 8 * q . k of key kt * 32 + (r & 3) + 8 (r >> 2) + 4 hl against query tq
+            if (kt == qb) {  // diagonal tile: position tq sees keys 0 .. tq (also hides the rows past P)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    sc[r] = key <= tq ? sc[r] : -INFINITY;
+                }
+            }
+            float mx = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = both_halves_max(mx);
+            // The reference point of the exponentials moves only when some query's maximum grew by more than 2^kDefer since it was
+            // set (fp32 accumulators: probabilities up to 2^kDefer lose nothing, and the planes split them exactly) — the rescale
+            // of the 32 output registers then runs on a few tiles of a row instead of all.  Everything at the old reference (O, l) is
+            // rescaled at the decision, before any probability of this tile exists.
+            if (__builtin_amdgcn_ballot_w64(mx > mrun + kDefer) != 0) {
+                const float mnew = fmaxf(mrun, mx);  // finite: every tile a query visits holds a key it sees
+                const float corr = __builtin_amdgcn_exp2f(mrun - mnew);
+                lrun *= corr;
+                mrun = mnew;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= corr;
+                    o1[r] *= corr;
+                }
+            }
+            float psum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = __builtin_amdgcn_exp2f(sc[r] - mrun);
+                psum += sc[r];
+            }
+            lrun += both_halves_sum(psum);
+            // ---- P^T fragments: registers 8 s' .. 8 s' + 7 are the lane's 8 keys of key slice s'
+            bf16x8 pf[3][2];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                uint32_t w[4][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3_pk(sc[8 * sp + 2 * e], sc[8 * sp + 2 * e + 1], w[e][0], w[e][1], w[e][2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pf[p][sp] = frag(w[0][p], w[1][p], w[2][p], w[3][p]);
+            }
+            // ---- O^T += V^T P^T: the lane's V fragment = keys 16 s' + 4 hl + {0..3, 8..11} of head dimension l31 (+ 32)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    bf16x8 vf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const char* a = kp + p * kVPlane + voff + 2 * dh * kVBlock + 16 * sp * 32;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 8 * 32));
+                        vf[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                    f32x16& o = dh ? o1 : o0;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PK[t]], pf[PQ[t]][sp], o, 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_tile(stg ^ 1, kr, vr);
+        __syncthreads();
+    }
+    if (!active || tq >= P) return;
+
+    // O^T: the lane holds d = (r & 3) + 8 (r >> 2) + 4 hl (+ 32 in o1) of its query
+    if (group_splits(g, nqb, nts) == 1) {  // softmax divides by the sum (ops.zig:239); the c_proj GEMM takes the rows as planes
+        const float inv = 1.0f / lrun;
+        bf16_t* hi = out + (row0 + tq) * kSplit * E + h * 64;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int d = 8 * gq + 4 * hl;
+            store_split4(hi + d, E, f32x4{o0[gq * 4] * inv, o0[gq * 4 + 1] * inv, o0[gq * 4 + 2] * inv, o0[gq * 4 + 3] * inv});
+            store_split4(hi + 32 + d, E, f32x4{o1[gq * 4] * inv, o1[gq * 4 + 1] * inv, o1[gq * 4 + 2] * inv, o1[gq * 4 + 3] * inv});
+        }
+    } else {
+        float* pp = part + ((((size_t)b * H + h) * P + tq) * max_s + s) * 66;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int d = 8 * gq + 4 * hl;  // (66-float records: 8-byte aligned)
+            *reinterpret_cast<float2*>(pp + d) = float2{o0[gq * 4], o0[gq * 4 + 1]};
+            *reinterpret_cast<float2*>(pp + d + 2) = float2{o0[gq * 4 + 2], o0[gq * 4 + 3]};
+            *reinterpret_cast<float2*>(pp + 32 + d) = float2{o1[gq * 4], o1[gq * 4 + 1]};
+            *reinterpret_cast<float2*>(pp + 32 + d + 2) = float2{o1[gq * 4 + 2], o1[gq * 4 + 3]};
+        }
+        if (hl == 0) *reinterpret_cast<float2*>(pp + 64) = float2{mrun, lrun};
+    }
+}
+
+// The key ranges of a query meet: weights 2^(m_s - max m), sums in split order, one division; rows of groups that ran as one
+// range were finished by the attention kernel itself.  One thread = four head dimensions of one (sequence, head, query).
+__global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, int P, int E, int H, int B,
+                                                                 unsigned geo) {
+    const int nts = (int)(geo & 0xffu), max_s = (int)((geo >> 8) & 0xffu);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int d = (int)(i & 15) * 4;
+    const size_t rec = i >> 4;  // (b, h, q)
+    if (rec >= (size_t)B * H * P) return;
+    const int q = (int)(rec % P), h = (int)((rec / P) % H), b = (int)(rec / ((size_t)P * H));
+    const int n = group_splits(q >> 7, (P + 31) >> 5, nts);
+    if (n == 1) return;
+    const float* pp = part + rec * max_s * 66;
+    float m = -INFINITY;
+    for (int s = 0; s < n; ++s) m = fmaxf(m, pp[s * 66 + 64]);
+    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+    float l = 0.0f;
+    for (int s = 0; s < n; ++s) {
+        const float w = __builtin_amdgcn_exp2f(pp[s * 66 + 64] - m);
+        l += w * pp[s * 66 + 65];
+        const float2 a = *reinterpret_cast<const float2*>(pp + s * 66 + d), c = *reinterpret_cast<const float2*>(pp + s * 66 + d + 2);
+        o.x += w * a.x; o.y += w * a.y; o.z += w * c.x; o.w += w * c.y;
+    }
+    const float inv = 1.0f / l;
+    store_split4(out + ((size_t)b * P + q) * kSplit * E + h * 64 + d, E, f32x4{o.x * inv, o.y * inv, o.z * inv, o.w * inv});
+}
+
+}  // namespace
+
+// out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t).  ws: fp32
+// workspace for the partials of split key ranges (B H P max_splits 66 floats; none needed when every group runs as one range).
+int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, hipStream_t s) {
+    static bool raised = false;
+    if (!raised) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        raised = true;
+    }
+    ZG_REQUIRE(E == H * 64, ZG_ERR_UNSUPPORTED, "attention prefill: head_dim must be 64 (n_embed %d, %d heads)", E, H);
+    const int nqb = (P + 31) / 32, ng = (nqb + 3) / 4;
+    // key tiles per workgroup: whole rows once the launch fills the chip about twice (2 workgroups fit a CU), else ranges of
+    // >= 4 tiles chosen so that it does — as long as the partials fit the workspace
+    int nts = 32 * ((nqb + 31) / 32);
+    {
+        const long groups = (long)B * H * ng;
+        const int env = getenv("ZGPT2_PF_ATTN_TILES") ? atoi(getenv("ZGPT2_PF_ATTN_TILES")) : 0;
+        if (env > 0) nts = env;
+        else
+            for (int cand = nts; cand >= 4; cand /= 2) {
+                long wgs = 0;
+                for (int g = 0; g < ng; ++g) wgs += group_splits(g, nqb, cand);
+                nts = cand;
+                if (wgs * B * H >= 512 || groups >= 512) break;
+            }
+        if (nts > 255) nts = 255;
+    }
+    int max_s = group_splits(ng - 1, nqb, nts);
+    if (max_s > 1 && (ws == nullptr || (size_t)B * H * P * max_s * 66 > ws_floats)) {  // no room for partials: whole rows
+        nts = nqb < 255 ? nqb : 255;
+        max_s = group_splits(ng - 1, nqb, nts);
+        ZG_REQUIRE(max_s == 1, ZG_ERR_UNSUPPORTED, "attention prefill: %d positions without a workspace", P);
+    }
+    ZG_REQUIRE(ng < 65536 && max_s < 256, ZG_ERR_UNSUPPORTED, "attention prefill: %d positions", P);
+    const unsigned geo = (unsigned)nts | ((unsigned)max_s << 8) | ((unsigned)ng << 16);
+    hipLaunchKernelGGL(attn_prefill_pl_kernel, dim3(H, B, ng * max_s), dim3(256), kLds, s, qkv, out, ws, P, E, geo);
+    ZG_HIP(hipGetLastError());
+    if (max_s > 1) {
+        const size_t n = (size_t)B * H * P * 16;
+        hipLaunchKernelGGL(attn_prefill_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, out, P, E, H, B, geo);
+        ZG_HIP(hipGetLastError());
+    }
+    return ZG_OK;
+}
+
+}  // namespace zg

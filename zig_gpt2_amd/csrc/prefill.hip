@@ -882,7 +882,7 @@ int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, voi
     ZG_REQUIRE(false, ZG_ERR_ARG, "prefill gemm: epilogue %d", epi);
 }
 
-int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s) {
+int launch_attn_prefill_f32(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s) {
     static bool raised = false;
     if (!raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel),

@@ -236,7 +236,9 @@ int launch_prefill_gemm(const bf16_t* A, const bf16_t* W, const float* bias, voi
                                                // kWeightPlanes: W is the plane-major three-term split [3][N][K] of an fp32 matrix
 constexpr int kWeightPlanes = 33;
 // out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t)
-int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s);
+// (attn_prefill.hip: bf16 matrix cores on exact plane splits; ws = fp32 workspace for the partials of split key ranges)
+int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, hipStream_t s);
+int launch_attn_prefill_f32(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s);  // the fp32-MFMA kernel it replaces (A/B)
 
 // GPT.sample tail: in-place softmax(logits / temp) per sequence + inverse-CDF draw with uniform u[b].
 int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s);
@@ -274,6 +276,9 @@ struct EmbedArgs {
     unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
 };
 int launch_embed_step(const EmbedArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------ multi-GPU (dist.hip)
+int dist_broadcast(void* buf, size_t bytes, int root, hipStream_t s);  // in place, over the communicator of zg_dist_init
 
 // ------------------------------------------------------------------------------------ decode prefetcher (prefetch.hip)
 enum PfKind { PF_NONE = 0, PF_WEIGHTS = 1, PF_KV = 2 };

@@ -9,11 +9,22 @@
 //
 //   zgpt2_main <tiny|tiny3|nano-char|124M> <weight_seed | raw weight directory> <tok,tok,...> <n_steps> [--model-tier]
 // prints the tokens after every step on one line (prompt tokens included, main.zig:339-340).
+//   zgpt2_main <model> <weights> "<tok,tok,...;tok,...;...>" <n_steps> --gpus N [--plan]
+// the multi-GPU case: the ';'-separated prompts are independent units, block-partitioned over N processes, one
+// per GPU (rank r on device r); rank 0 loads the weights and ONE RCCL broadcast of the weight arena carries them to the
+// others (zg_gpt_broadcast_weights); every rank generates its prompts in lock step; one line per prompt, in prompt order.
+// --plan prints the partition and exits without touching a GPU.
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <array>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -231,6 +242,132 @@ static std::vector<size_t> generate_model_tier(const GPTConfig& c, const Weights
     return out;
 }
 
+// ---------------------------------------------------------------- multi-GPU: prompts sharded, weights broadcast once
+// prompt indices of `rank`: contiguous blocks whose sizes differ by at most one (zig_gpt2_amd/shard.py shard_prompts)
+static void shard_prompts(size_t n_prompts, int world, int rank, size_t& begin, size_t& count) {
+    const size_t base = n_prompts / world, extra = n_prompts % world;
+    begin = rank * base + std::min<size_t>(rank, extra);
+    count = base + ((size_t)rank < extra ? 1 : 0);
+}
+
+static bool read_all(int fd, void* buf, size_t n) {
+    char* p = static_cast<char*>(buf);
+    while (n > 0) {
+        const ssize_t r = read(fd, p, n);
+        if (r <= 0) return false;
+        p += r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+
+// one rank: its device, the communicator, the handle, the weights (loaded on rank 0, received elsewhere), its prompts
+static int run_rank(int rank, int world, const GPTConfig& c, const std::string& wsrc, bool from_dir, uint64_t seed,
+                    const std::vector<std::vector<size_t>>& prompts, size_t n_steps, int id_in_fd, const std::vector<int>& id_out_fds, int out_fd) {
+    try {
+        ops::check(zg_init(rank));
+        unsigned char id[ZG_DIST_ID_BYTES];
+        if (rank == 0) {
+            ops::check(zg_dist_unique_id(id, sizeof id));
+            for (int fd : id_out_fds)
+                if (write(fd, id, sizeof id) != (ssize_t)sizeof id) throw std::runtime_error("id pipe");
+        } else if (!read_all(id_in_fd, id, sizeof id)) {
+            throw std::runtime_error("rank 0 sent no communicator id");
+        }
+        ops::check(zg_dist_init(id, sizeof id, rank, world));
+        size_t begin, count;
+        shard_prompts(prompts.size(), world, rank, begin, count);
+        // every rank creates the same handle shape (the weight region of the arena does not depend on the batch)
+        zg_gpt_config cfg{c.vocab_size, c.context_size, c.n_layer, c.n_heads, c.n_embed};
+        zg_gpt* g = nullptr;
+        ops::check(zg_gpt_create(&g, &cfg, std::max<size_t>(count, 1), ZG_GPT_WEIGHTS_BF16));
+        if (rank == 0) {  // load_gpt (main.zig:304-314) on one GPU only
+            const Weights w = from_dir ? Weights(c, wsrc) : Weights(c, seed);
+            const Buf* top[4] = {&w.wte, &w.wpe, &w.ln_f_g, &w.ln_f_b};
+            for (int s = 0; s < 4; ++s) ops::check(zg_gpt_load_tensor(g, s, top[s]->data(), top[s]->size()));
+            for (size_t l = 0; l < c.n_layer; ++l)
+                for (int s = 0; s < 12; ++s) ops::check(zg_gpt_load_block_tensor(g, l, s, w.h[l].t[s].data(), w.h[l].t[s].size()));
+        }
+        float ms = 0.f;
+        ops::check(zg_gpt_broadcast_weights(g, 0, &ms));
+        if (rank == 0) fprintf(stderr, "weights broadcast to %d rank(s) in %.3f ms\n", world, ms);
+        std::vector<size_t> out(count * n_steps);
+        if (count > 0) {
+            size_t stride = 0;
+            for (size_t i = 0; i < count; ++i) stride = std::max(stride, prompts[begin + i].size());
+            std::vector<size_t> flat(count * stride, 0), lens(count);
+            for (size_t i = 0; i < count; ++i) {
+                lens[i] = prompts[begin + i].size();
+                std::copy(prompts[begin + i].begin(), prompts[begin + i].end(), flat.begin() + i * stride);
+            }
+            ops::check(zg_gpt_generate_greedy(g, flat.data(), stride, lens.data(), n_steps, out.data(), out.size()));
+        }
+        zg_gpt_destroy(g);
+        ops::check(zg_dist_finalize());
+        if (!out.empty() && write(out_fd, out.data(), out.size() * sizeof(size_t)) != (ssize_t)(out.size() * sizeof(size_t)))
+            throw std::runtime_error("result pipe");
+    } catch (const std::exception& e) {
+        fprintf(stderr, "rank %d: error: %s\n", rank, e.what());
+        return 1;
+    }
+    return 0;
+}
+
+static int main_multi_gpu(int world, bool plan_only, const GPTConfig& c, const std::string& wsrc, bool from_dir, uint64_t seed,
+                          const std::vector<std::vector<size_t>>& prompts, size_t n_steps) {
+    if (plan_only) {
+        for (int r = 0; r < world; ++r) {
+            size_t begin, count;
+            shard_prompts(prompts.size(), world, r, begin, count);
+            printf("rank %d:", r);
+            for (size_t i = 0; i < count; ++i) printf(" %zu", begin + i);
+            printf("\n");
+        }
+        return 0;
+    }
+    // The ranks are started BEFORE anything touches a GPU (a process that has initialised HIP must not fork workers).  Pipes:
+    // rank 0 -> every other rank (the 128-byte communicator id), every rank -> this process (its token rows).
+    std::vector<int> id_rd(world, -1), id_wr, out_rd(world, -1);
+    std::vector<pid_t> pids(world);
+    std::vector<std::array<int, 2>> idp(world), outp(world);
+    for (int r = 0; r < world; ++r)
+        if ((r > 0 && pipe(idp[r].data()) != 0) || pipe(outp[r].data()) != 0) return 1;
+    for (int r = 1; r < world; ++r) id_wr.push_back(idp[r][1]);
+    for (int r = 0; r < world; ++r) {
+        pids[r] = fork();
+        if (pids[r] < 0) return 1;
+        if (pids[r] == 0) {
+            for (int q = 0; q < world; ++q) close(outp[q][0]);
+            const int rc = run_rank(r, world, c, wsrc, from_dir, seed, prompts, n_steps, r > 0 ? idp[r][0] : -1, r == 0 ? id_wr : std::vector<int>(),
+                                    outp[r][1]);
+            _exit(rc);
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        close(outp[r][1]);
+        if (r > 0) {
+            close(idp[r][0]);
+            close(idp[r][1]);
+        }
+    }
+    int failed = 0;
+    for (int r = 0; r < world; ++r) {
+        size_t begin, count;
+        shard_prompts(prompts.size(), world, r, begin, count);
+        std::vector<size_t> rows(count * n_steps);
+        const bool ok = rows.empty() || read_all(outp[r][0], rows.data(), rows.size() * sizeof(size_t));
+        int status = 0;
+        waitpid(pids[r], &status, 0);
+        if (!ok || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+            ++failed;
+            continue;
+        }
+        for (size_t i = 0; i < count; ++i)
+            for (size_t s = 0; s < n_steps; ++s) printf("%zu%s", rows[i * n_steps + s], s + 1 < n_steps ? " " : "\n");
+    }
+    return failed ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) {
         fprintf(stderr, "usage: %s <tiny|tiny3|nano-char|124M> <seed | raw weight dir> <tok,tok,...> <n_steps> [--model-tier]\n", argv[0]);
@@ -246,9 +383,33 @@ int main(int argc, char** argv) {
     const std::string wsrc = argv[2];  // digits: seed of the synthetic weights; anything else: a raw weight directory
     const bool from_dir = wsrc.find_first_not_of("0123456789") != std::string::npos;
     const uint64_t seed = from_dir ? 0 : strtoull(argv[2], nullptr, 10);
+    const size_t n_steps = strtoull(argv[4], nullptr, 10);
+    int gpus = 0;
+    bool plan_only = false;
+    for (int i = 5; i < argc; ++i) {
+        if (std::string(argv[i]) == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (std::string(argv[i]) == "--plan") plan_only = true;
+    }
+    if (gpus > 0) {
+        std::vector<std::vector<size_t>> prompts;
+        std::string all = argv[3];
+        size_t pos = 0;
+        while (pos <= all.size()) {
+            const size_t end = std::min(all.find(';', pos), all.size());
+            std::vector<size_t> one;
+            std::string item = all.substr(pos, end - pos);
+            for (char* p = strtok(item.data(), ","); p; p = strtok(nullptr, ",")) one.push_back(strtoull(p, nullptr, 10));
+            if (one.empty()) {
+                fprintf(stderr, "empty prompt\n");
+                return 2;
+            }
+            prompts.push_back(one);
+            pos = end + 1;
+        }
+        return main_multi_gpu(gpus, plan_only, config, wsrc, from_dir, seed, prompts, n_steps);
+    }
     std::vector<size_t> inputs;
     for (char* p = strtok(argv[3], ","); p; p = strtok(nullptr, ",")) inputs.push_back(strtoull(p, nullptr, 10));
-    const size_t n_steps = strtoull(argv[4], nullptr, 10);
     const bool model_tier = argc > 5 && std::string(argv[5]) == "--model-tier";
     try {
         ops::check(zg_init(0));
