@@ -136,6 +136,21 @@ unsigned long long zg_debug_gemm_launches(void);
 /* Diagnostic: shader-clock stamps {count, start, end} of workgroup 0 / wave 0 of the last GEMM launched with
  * ZGPT2_GEMM_DBG bit 256 (tools/microbench/gemm_bench.cpp: cycles vs wall time = the clock the chip ran at). */
 int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words);
+/* Diagnostic / test entry: ONE whole-prompt Linear exactly as zg_gpt_prefill launches it (src/ops.zig:21-46 for M = batch x
+ * prompt rows).  A = the activation planes [M][3 K] bf16 (hi | mid | lo: the exact split of the fp32 rows), W = bf16 weights
+ * [N][K], all device pointers.  epilogue: 0 fp32 C[M][N] = A W^T + bias; 1 C[M][N] += ... (residual add; ws required);
+ * 2 bf16 planes C[M][3 N] of gelu(...).  force_kernel: 0 = the library's choice, 1 = the persistent four-wave GEMM
+ * (gemm_s4.hip; slices = its K slices for epilogue 1, 0 = chosen), 2 = the 128-row prompt GEMM (prefill.hip).  ws: fp32
+ * workspace of ws_floats elements for partial slabs.  The cache-append epilogue is exercised through zg_gpt_prefill. */
+int zg_debug_prefill_linear(const uint16_t* A_planes, const uint16_t* W, const float* bias_or_null, void* C, size_t M, size_t N,
+                            size_t K, int epilogue, int force_kernel, int slices, float* ws, size_t ws_floats);
+/* Diagnostic / test entry: the causal prompt attention of zg_gpt_prefill alone (scaled_dot_product_attention of src/ops.zig:249-307
+ * for all n_tokens positions of `batch` sequences at once).  qkv: fp32 [batch n_tokens][3 n_embed] rows (q | k | v columns);
+ * out: bf16 planes [batch n_tokens][3 n_embed] = hi | mid | lo of the attention output; k_cache / v_cache: NULL (K and V are the
+ * qkv columns) or head-major fp32 caches [batch][heads][ctx][64] holding the same rows; ws: fp32 workspace for the partials of
+ * split key ranges (may be NULL: whole rows per workgroup).  Device pointers. */
+int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t n_tokens, size_t n_embed, size_t n_heads,
+                          const float* k_cache, const float* v_cache, size_t ctx, float* ws, size_t ws_floats);
 /* Diagnostic: name of the kernel instantiation the last decode-kernel launcher of this thread picked (launches recorded
  * into a graph count; bench.py reports it as the symbol of the roofline kernel). */
 int zg_debug_last_kernel(char* out, size_t n);

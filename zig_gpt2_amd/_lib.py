@@ -46,6 +46,8 @@ SIGNATURES = {
     "zg_debug_gemm_launches": (C.c_ulonglong, []),
     "zg_debug_gemm_stamps": (C.c_int, [vp, sz]),
     "zg_debug_last_kernel": (C.c_int, [C.c_char_p, sz]),
+    "zg_debug_attn_prefill": (C.c_int, [vp, vp, sz, sz, sz, sz, vp, vp, sz, vp, sz]),
+    "zg_debug_prefill_linear": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, C.c_int, C.c_int, C.c_int, vp, sz]),
     "zg_linear_forward": (C.c_int, [sz, sz, vp, vp, vp, sz, vp, sz]),
     "zg_embedding_forward": (C.c_int, [sz, vp, sz, vp, sz, vp, sz]),
     "zg_layernorm_forward": (C.c_int, [sz, vp, vp, C.c_float, vp, sz]),

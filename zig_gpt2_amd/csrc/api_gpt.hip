@@ -593,7 +593,9 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
                                    g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
         if (getenv("ZGPT2_PF_ATTN_OLD")) ZG_TRY(launch_attn_prefill_f32(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
-        else ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, g->pf_ws, g->pf_ws_floats, s));
+        else  // (an fp32 cache is read directly: the c_attn epilogue then need not store the k / v columns of qkv)
+            ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, g->pf_ws, g->pf_ws_floats, g->kv_mode == 0 ? (const float*)y.k_cache : nullptr,
+                                       g->kv_mode == 0 ? (const float*)y.v_cache : nullptr, (int)C, s));
         const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_proj_p : (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
                                    g->pf_ws_floats, &ln2, s, nullptr, np));

@@ -376,6 +376,30 @@ int zg_gemm_bf16_nt(const uint16_t* A, const uint16_t* B, const float* bias_or_n
                                ctx().stream);
 }
 
+int zg_debug_prefill_linear(const uint16_t* A, const uint16_t* W, const float* bias, void* C, size_t M, size_t N, size_t K, int epilogue,
+                            int force_kernel, int slices, float* ws, size_t ws_floats) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(A && W && C && is_device_ptr(A) && is_device_ptr(W) && is_device_ptr(C) && (!bias || is_device_ptr(bias)) && (!ws || is_device_ptr(ws)),
+               ZG_ERR_ARG, "debug_prefill_linear: device pointers");
+    ZG_REQUIRE(M < (1u << 30) && N < (1u << 30) && K < (1u << 30) && epilogue >= 0 && epilogue <= 2, ZG_ERR_ARG, "debug_prefill_linear: arguments");
+    const int epi = epilogue == 0 ? PF_F32 : epilogue == 1 ? PF_RESID : PF_GELU_SPLIT;
+    prefill_force_route(force_kernel, slices);
+    const int st = launch_prefill_gemm(A, W, bias, C, (int)M, (int)N, (int)K, epi == PF_GELU_SPLIT ? 0 : (int)N, epi, ws, ws_floats, nullptr, ctx().stream);
+    prefill_force_route(0, 0);
+    return st;
+}
+
+int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t n_tokens, size_t n_embed, size_t n_heads, const float* k_cache,
+                          const float* v_cache, size_t ctx_len, float* ws, size_t ws_floats) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(qkv && out && is_device_ptr(qkv) && is_device_ptr(out) && (!k_cache || (v_cache && is_device_ptr(k_cache) && is_device_ptr(v_cache))) &&
+                   (!ws || is_device_ptr(ws)),
+               ZG_ERR_ARG, "debug_attn_prefill: device pointers");
+    ZG_REQUIRE(batch >= 1 && n_tokens >= 1 && batch * n_tokens < (1u << 24) && n_embed < (1u << 16) && (!k_cache || ctx_len >= n_tokens), ZG_ERR_ARG,
+               "debug_attn_prefill: arguments");
+    return launch_attn_prefill(qkv, out, (int)batch, (int)n_tokens, (int)n_embed, (int)n_heads, ws, ws_floats, k_cache, v_cache, (int)ctx_len, ctx().stream);
+}
+
 unsigned long long zg_debug_gemm_launches(void) { return gemm_mfma_launch_count(); }
 int zg_debug_gemm_stamps(unsigned long long* out, size_t n_words) { return gemm_debug_stamps(out, n_words); }
 int zg_debug_last_kernel(char* out, size_t n) {

@@ -18,6 +18,8 @@
 // products (the k index of an MFMA step only has to agree between its operands: the keys a lane holds after S^T are the keys
 // its P fragment multiplies).  Long rows of few sequences are cut into key ranges over several workgroups whose (m, l, O)
 // partials a small kernel merges (one prompt of 1023 tokens would otherwise be 96 workgroups of up to 32 tiles).
+#include <type_traits>
+
 #include "zg_kernels.h"
 
 namespace zg {
@@ -33,9 +35,7 @@ constexpr int kKPlane = 32 * 128;        // one K plane of a tile: [32 keys][64 
 constexpr int kVBlock = 32 * 32 + 128;   // one 16-d block of a V plane: [32 keys][16 d] bf16, + 128 B: the two blocks a half-wave reads
                                          // in one ds_read_b64_tr_b16 then lie 288 dwords apart — the two halves of the 64 banks
 constexpr int kVPlane = 4 * kVBlock;
-constexpr int kVOff = 3 * kKPlane;
-constexpr int kStage = 3 * kKPlane + 3 * kVPlane;  // 26112 B
-constexpr int kLds = 2 * kStage;
+constexpr int kLds = 2 * 3 * kKPlane + 2 * 3 * kVPlane;  // K ring + V ring, two slots each: 52224 B
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDefer = 8.0f;  // log2 units
 
@@ -65,8 +65,26 @@ __host__ __device__ inline int group_tiles(int g, int nqb) { return 4 * g + 4 < 
 __host__ __device__ inline int group_splits(int g, int nqb, int nts) { return (group_tiles(g, nqb) + nts - 1) / nts; }
 
 // geo = key tiles per split | most splits of a group << 8 | query groups << 16.  part: [B][H][P][max splits][66] (O^T[64], m, l).
+//
+// One instruction stream per wave, software-pipelined over the key tiles so that the matrix pipe and the vector ALU of a SIMD
+// work side by side WITHIN a wave (the first version ran S -> softmax -> split -> PV -> staging in sequence: 48 MFMAs = 1.5 k
+// cycles of a 6.4 k-cycle tile, 45 % matrix-busy with two waves per SIMD):
+//   phase A   S^T(t + 1) = K(t + 1) Q^T  (24 MFMAs)   beside   exp / sum / three-plane split of tile t's scores
+//   phase B   O^T += V(t)^T P(t)^T       (24 MFMAs)   beside   split + LDS write of the tiles in flight: K(t + 2), V(t + 1)
+// so K runs one tile ahead of V through its own two-slot ring; one barrier per tile.  The loop body has no branch (tiles above a
+// wave's diagonal are computed fully masked: its siblings need the tile anyway, the barrier would make it wait for them), only
+// the rare rescale of the running maximum sits in front of phase A.
+// K / V rows of (sequence b, head h), key t: 64 floats at ksrc / vsrc + b kv.stride_b + h kv.stride_h + t kv.stride_t bytes — the k / v
+// columns of the qkv rows, or the head-major fp32 caches the c_attn epilogue has just appended to (then the Linear need not
+// store those columns at all).
+struct AttnKv {
+    const char* ksrc;
+    const char* vsrc;
+    size_t stride_b, stride_h;
+    unsigned stride_t;
+};
 __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ part,
-                                                                 int P, int E, unsigned geo) {
+                                                                 int P, int E, unsigned geo, const AttnKv kv) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,8 +98,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
     const int nqb = (P + 31) >> 5;
     const int kt0 = s * nts, kt1 = min((s + 1) * nts, group_tiles(g, nqb));
     if (kt0 >= kt1) return;
+    const int n_t = kt1 - kt0;
     const int qb = 4 * g + wave, tq = qb * 32 + l31;
-    const bool active = qb < nqb;
     const size_t row0 = (size_t)b * P;
     const int ld = 3 * E;
 
@@ -106,135 +124,216 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
 
     // staging: wave w fetches keys 8 w .. 8 w + 7 of a tile.  K: 16 lanes x 16 B = one 256-byte head row per key (its LDS row is 128
     // contiguous bytes: 32 banks).  V: a 16-lane group takes ONE 16-d block of four keys, the 128 contiguous bytes that block is in
-    // LDS (with K's map the four blocks of a row, 288 dwords apart, met on the same banks: a third of all LDS cycles were conflicts)
+    // LDS (with K's map the four blocks of a row, 288 dwords apart, met on the same banks: a third of all LDS cycles were conflicts).
+    // The loads go through a buffer descriptor — the lane's part of the address is fixed, the tile a scalar offset — and rows past
+    // the last sequence read as zero (rows past P of another sequence read its first rows: finite, and masked).
+    // The descriptors end behind key P - 1 of this (sequence, head): later keys read as zero (a cache row past the prompt may hold
+    // anything, and 0 x NaN would poison the second product; the scores of such keys are masked anyway).
+    const size_t kv_base = (size_t)b * kv.stride_b + (size_t)h * kv.stride_h;
+    const unsigned kv_bytes = (unsigned)(P - 1) * kv.stride_t + 256u;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kv.ksrc + kv_base), 0, kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kv.vsrc + kv_base), 0, kv_bytes, 0x00020000);
     const int skey = wave * 8 + (lane >> 4), sd0 = (lane & 15) * 4;
     const int vkey = wave * 8 + ((lane & 15) >> 2), vd0 = 16 * (lane >> 4) + 4 * (lane & 3);
-    auto load_tile = [&](int kt, f32x4(&kr)[2], f32x4(&vr)[2]) {
+    const unsigned kvo = (unsigned)skey * kv.stride_t + (unsigned)sd0 * 4u, vvo = (unsigned)vkey * kv.stride_t + (unsigned)vd0 * 4u;
+    const unsigned row4 = 4u * kv.stride_t;  // four keys further on
+    auto tile_off = [&](int kt) { return (unsigned)kt * 32u * kv.stride_t; };
+    auto load_k = [&](int kt, u32x4(&kr)[2]) {
+        const unsigned so = tile_off(kt);
+        kr[0] = __builtin_amdgcn_raw_buffer_load_b128(rk, kvo, so, 0);
+        kr[1] = __builtin_amdgcn_raw_buffer_load_b128(rk, kvo + row4, so, 0);
+    };
+    auto load_v = [&](int kt, u32x4(&vr)[2]) {
+        const unsigned so = tile_off(kt);
+        vr[0] = __builtin_amdgcn_raw_buffer_load_b128(rv, vvo, so, 0);
+        vr[1] = __builtin_amdgcn_raw_buffer_load_b128(rv, vvo + row4, so, 0);
+    };
+    char* const kring = lds;                    // [2 slots][3 planes][32 keys][64 d]
+    char* const vring = lds + 2 * 3 * kKPlane;  // [2 slots][3 planes][4 d blocks][32 keys][16 d]
+    const int kaddr = skey * 128 + (((sd0 >> 3) ^ ((skey >> 1) & 7)) << 4) + ((sd0 >> 2) & 1) * 8;  // (key + 4: same swizzle term + 2)
+    const int kaddr1 = (skey + 4) * 128 + (((sd0 >> 3) ^ (((skey + 4) >> 1) & 7)) << 4) + ((sd0 >> 2) & 1) * 8;
+    const int vaddr = (vd0 >> 4) * kVBlock + vkey * 32 + (vd0 & 15) * 2;
+    auto store_k = [&](int slot, const u32x4(&kr)[2]) {
+        char* st = kring + slot * 3 * kKPlane;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            kr[j] = *reinterpret_cast<const f32x4*>(qkv + (row0 + min(kt * 32 + skey + 4 * j, P - 1)) * ld + h * 64 + sd0 + E);
-            vr[j] = *reinterpret_cast<const f32x4*>(qkv + (row0 + min(kt * 32 + vkey + 4 * j, P - 1)) * ld + h * 64 + vd0 + 2 * E);
+            const f32x4 v = __builtin_bit_cast(f32x4, kr[j]);
+            uint32_t a[3], c[3];
+            split3_pk(v.x, v.y, a[0], a[1], a[2]);
+            split3_pk(v.z, v.w, c[0], c[1], c[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(st + p * kKPlane + (j ? kaddr1 : kaddr)) = u32x2{a[p], c[p]};
         }
     };
-    auto store_tile = [&](int stage, const f32x4(&kr)[2], const f32x4(&vr)[2]) {
-        char* st = lds + stage * kStage;
+    auto store_v = [&](int slot, const u32x4(&vr)[2]) {
+        char* st = vring + slot * 3 * kVPlane;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int key = skey + 4 * j;
-            const int kaddr = key * 128 + (((sd0 >> 3) ^ ((key >> 1) & 7)) << 4) + ((sd0 >> 2) & 1) * 8;
-            const int vaddr = kVOff + (vd0 >> 4) * kVBlock + (vkey + 4 * j) * 32 + (vd0 & 15) * 2;
+            const f32x4 v = __builtin_bit_cast(f32x4, vr[j]);
             uint32_t a[3], c[3];
-            split3_pk(kr[j].x, kr[j].y, a[0], a[1], a[2]);
-            split3_pk(kr[j].z, kr[j].w, c[0], c[1], c[2]);
+            split3_pk(v.x, v.y, a[0], a[1], a[2]);
+            split3_pk(v.z, v.w, c[0], c[1], c[2]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(st + p * kKPlane + kaddr) = u32x2{a[p], c[p]};
-            split3_pk(vr[j].x, vr[j].y, a[0], a[1], a[2]);
-            split3_pk(vr[j].z, vr[j].w, c[0], c[1], c[2]);
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(st + p * kVPlane + vaddr + j * 4 * 32) = u32x2{a[p], c[p]};
+        }
+    };
+
+    // fragment addresses: K rows by key = l31; V blocks by the 16-lane group (d block) and the lane's place in the 4 x 16 read
+    const int koff = l31 * 128, kswz = (l31 >> 1) & 7;
+    const int voff = ((lane >> 4) & 1) * kVBlock + (4 * hl + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+    constexpr int PK[6] = {2, 0, 1, 1, 0, 0}, PQ[6] = {0, 2, 1, 0, 1, 0};  // the six plane pairs (k or v plane, q or p plane), smallest first
+    // S^T = K Q^T of the tile in K slot `slot`, as TWO accumulator chains taking the plane pairs in turn: an MFMA that follows
+    // another one on the same accumulator must follow it directly (anything issued between them costs the accumulate forwarding, ~43
+    // cycles), whereas between MFMAs on different accumulators ~5 other instructions are free — which is where this wave's vector
+    // work goes (MI355X_MICROARCH.md, per-instruction constants).  The caller adds the two halves.
+    auto s_tile = [&](int slot, f32x16& sa, f32x16& sb) {
+        const char* kp = kring + slot * 3 * kKPlane;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(st + p * kVPlane + vaddr) = u32x2{a[p], c[p]};
+        for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(kp + p * kKPlane + koff + (((2 * ks + hl) ^ kswz) << 4));
+#pragma unroll
+            for (int t = 0; t < 6; t += 2) {
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t]], qf[PQ[t]][ks], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t + 1]], qf[PQ[t + 1]][ks], sb, 0, 0, 0);
+            }
         }
     };
 
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
-    float mrun = -INFINITY, lrun = 0.0f;  // running maximum (in log2 units) and sum of this lane's query
+    float mrun = -INFINITY, lrun = 0.0f;  // reference point of the exponentials (log2 units) and running sum of this lane's query
 
-    // fragment addresses: K rows by key = l31; V blocks by the 16-lane group (d block) and the lane's place in the 4 x 16 read
-    const int koff = l31 * 128, kswz = (l31 >> 1) & 7;
-    const int voff = kVOff + ((lane >> 4) & 1) * kVBlock + (4 * hl + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+    // ---- prologue: K(0), V(0), K(1) staged; S(0); K(2), V(1) in flight
+    u32x4 kr[2], vr[2];
+    f32x16 sc;
+    {
+        u32x4 k1[2];
+        load_k(kt0, kr);
+        load_v(kt0, vr);
+        load_k(kt0 + 1, k1);
+        store_k(0, kr);
+        store_v(0, vr);
+        store_k(1, k1);
+        load_k(kt0 + 2, kr);
+        load_v(kt0 + 1, vr);
+        __syncthreads();
+        f32x16 sb;
+        s_tile(0, sc, sb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] += sb[r];
+        __syncthreads();  // (K slot 0 is rewritten in the first tile's phase B: every wave must have read K(0) out)
+    }
 
-    f32x4 kr[2], vr[2];
-    load_tile(kt0, kr, vr);
-    store_tile(0, kr, vr);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int stg = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) load_tile(kt + 1, kr, vr);
-        if (active && kt <= qb) {
-            const char* kp = lds + stg * kStage;
-            // ---- S^T = K Q^T over the six plane pairs, smallest terms first
-            bf16x8 kf[3][4];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[p][ks] = *reinterpret_cast<const bf16x8*>(kp + p * kKPlane + koff + (((2 * ks + hl) ^ kswz) << 4));
-            f32x16 sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
-            constexpr int PK[6] = {2, 0, 1, 1, 0, 0}, PQ[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t]][ks], qf[PQ[t]][ks], sc, 0, 0, 0);
-            // sc[r] = log2(e) / 8 * q . k of key kt * 32 + (r & 3) + 8 (r >> 2) + 4 hl against query tq
-            if (kt == qb) {  // diagonal tile: position tq sees keys 0 .. tq (also hides the rows past P)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    sc[r] = key <= tq ? sc[r] : -INFINITY;
-                }
-            }
-            float mx = sc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-            mx = both_halves_max(mx);
-            // The reference point of the exponentials moves only when some query's maximum grew by more than 2^kDefer since it was
-            // set (fp32 accumulators: probabilities up to 2^kDefer lose nothing, and the planes split them exactly) — the rescale
-            // of the 32 output registers then runs on a few tiles of a row instead of all.  Everything at the old reference (O, l) is
-            // rescaled at the decision, before any probability of this tile exists.
-            if (__builtin_amdgcn_ballot_w64(mx > mrun + kDefer) != 0) {
-                const float mnew = fmaxf(mrun, mx);  // finite: every tile a query visits holds a key it sees
-                const float corr = __builtin_amdgcn_exp2f(mrun - mnew);
-                lrun *= corr;
-                mrun = mnew;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o0[r] *= corr;
-                    o1[r] *= corr;
-                }
-            }
-            float psum = 0.0f;
+    // one tile: i = its index in the range (slot parity SLOT = i & 1), WITH_S = a next tile exists
+    auto body = [&](auto SLOT_T, auto WITH_S_T, int i) {
+        constexpr int SLOT = decltype(SLOT_T)::value;
+        constexpr bool WITH_S = decltype(WITH_S_T)::value;
+        const int kt = kt0 + i;
+        // sc[r] = log2(e) / 8 * q . k of key kt * 32 + (r & 3) + 8 (r >> 2) + 4 hl against query tq
+        if (kt >= qb) {  // diagonal tile (and the tiles past it, which a sibling wave needs): position tq sees keys 0 .. tq
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sc[r] = __builtin_amdgcn_exp2f(sc[r] - mrun);
-                psum += sc[r];
-            }
-            lrun += both_halves_sum(psum);
-            // ---- P^T fragments: registers 8 s' .. 8 s' + 7 are the lane's 8 keys of key slice s'
-            bf16x8 pf[3][2];
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                uint32_t w[4][3];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split3_pk(sc[8 * sp + 2 * e], sc[8 * sp + 2 * e + 1], w[e][0], w[e][1], w[e][2]);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) pf[p][sp] = frag(w[0][p], w[1][p], w[2][p], w[3][p]);
-            }
-            // ---- O^T += V^T P^T: the lane's V fragment = keys 16 s' + 4 hl + {0..3, 8..11} of head dimension l31 (+ 32)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-#pragma unroll
-                for (int dh = 0; dh < 2; ++dh) {
-                    bf16x8 vf[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const char* a = kp + p * kVPlane + voff + 2 * dh * kVBlock + 16 * sp * 32;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 8 * 32));
-                        vf[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    }
-                    f32x16& o = dh ? o1 : o0;
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PK[t]], pf[PQ[t]][sp], o, 0, 0, 0);
-                }
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                sc[r] = key <= tq ? sc[r] : -INFINITY;
             }
         }
-        if (more) store_tile(stg ^ 1, kr, vr);
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+        mx = both_halves_max(mx);
+        // The reference point of the exponentials moves only when some query's maximum grew by more than 2^kDefer since it was
+        // set (fp32 accumulators: probabilities up to 2^kDefer lose nothing, and the planes split them exactly) — the rescale
+        // of the 32 output registers then runs on a few tiles of a row instead of all.  Everything at the old reference (O, l) is
+        // rescaled at the decision, before any probability of this tile exists.
+        if (__builtin_amdgcn_ballot_w64(mx > mrun + kDefer) != 0) {
+            const float mnew = fmaxf(mrun, mx);
+            const float corr = mnew == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(mrun - mnew);  // (a row that has seen no key yet)
+            lrun *= corr;
+            mrun = mnew;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= corr;
+                o1[r] *= corr;
+            }
+        }
+        // ---- phase A: the next tile's scores beside this tile's probabilities
+        f32x16 sn, sm;
+        if constexpr (WITH_S) s_tile(SLOT ^ 1, sn, sm);
+#ifdef ZG_ATTN_DBG_BAR2
         __syncthreads();
+#endif
+        const float mref = fmaxf(mrun, -1e30f);  // (all keys masked so far: 2^(-inf - mref) = 0, not NaN)
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = __builtin_amdgcn_exp2f(sc[r] - mref);
+            psum += sc[r];
+        }
+        lrun += both_halves_sum(psum);
+        bf16x8 pf[3][2];  // P^T fragments: registers 8 s' .. 8 s' + 7 are the lane's 8 keys of key slice s'
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            uint32_t w[4][3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3_pk(sc[8 * sp + 2 * e], sc[8 * sp + 2 * e + 1], w[e][0], w[e][1], w[e][2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) pf[p][sp] = frag(w[0][p], w[1][p], w[2][p], w[3][p]);
+        }
+        // ---- phase B: O^T += V^T P^T beside the staging of the tiles in flight.  The lane's V fragment = keys 16 s' + 4 hl + {0..3, 8..11}
+        // of head dimension l31 (+ 32).
+        const char* vp = vring + SLOT * 3 * kVPlane + voff;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            bf16x8 vf[2][3];
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const char* a = vp + p * kVPlane + 2 * dh * kVBlock + 16 * sp * 32;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 8 * 32));
+                    vf[dh][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {  // the two halves of the head dimension in turn: two accumulator chains
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][PK[t]], pf[PQ[t]][sp], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][PK[t]], pf[PQ[t]][sp], o1, 0, 0, 0);
+            }
+        }
+#ifdef ZG_ATTN_DBG_BAR
+        __syncthreads();
+#endif
+        store_k(SLOT, kr);       // K(i + 2): the slot K(i) left in the previous tile's phase A
+        store_v(SLOT ^ 1, vr);   // V(i + 1): the slot V(i - 1) left in the previous tile's phase B
+        load_k(kt + 3, kr);
+        load_v(kt + 2, vr);
+        if constexpr (WITH_S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = sn[r] + sm[r];
+        }
+        __syncthreads();
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        int i = 0;
+        for (; i + 2 < n_t; i += 2) {
+            body(std::integral_constant<int, 0>{}, T{}, i);
+            body(std::integral_constant<int, 1>{}, T{}, i + 1);
+        }
+        if (n_t - i == 2) {
+            body(std::integral_constant<int, 0>{}, T{}, i);
+            body(std::integral_constant<int, 1>{}, F{}, i + 1);
+        } else {
+            body(std::integral_constant<int, 0>{}, F{}, i);
+        }
     }
-    if (!active || tq >= P) return;
+    if (qb >= nqb || tq >= P) return;
 
     // O^T: the lane holds d = (r & 3) + 8 (r >> 2) + 4 hl (+ 32 in o1) of its query
     if (group_splits(g, nqb, nts) == 1) {  // softmax divides by the sum (ops.zig:239); the c_proj GEMM takes the rows as planes
@@ -291,7 +390,10 @@ __global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const float* __
 
 // out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t).  ws: fp32
 // workspace for the partials of split key ranges (B H P max_splits 66 floats; none needed when every group runs as one range).
-int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, hipStream_t s) {
+// k_cache / v_cache != null: K and V come from the head-major fp32 caches [b][h][ctx][64] (positions 0 .. P - 1 just appended
+// by the c_attn epilogue) instead of the k / v columns of qkv.
+int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, const float* k_cache,
+                        const float* v_cache, int ctx, hipStream_t s) {
     static bool raised = false;
     if (!raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
@@ -323,7 +425,14 @@ int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int 
     }
     ZG_REQUIRE(ng < 65536 && max_s < 256, ZG_ERR_UNSUPPORTED, "attention prefill: %d positions", P);
     const unsigned geo = (unsigned)nts | ((unsigned)max_s << 8) | ((unsigned)ng << 16);
-    hipLaunchKernelGGL(attn_prefill_pl_kernel, dim3(H, B, ng * max_s), dim3(256), kLds, s, qkv, out, ws, P, E, geo);
+    AttnKv kv;
+    if (k_cache != nullptr) {  // head-major fp32 caches [b][h][ctx][64]
+        kv = AttnKv{reinterpret_cast<const char*>(k_cache), reinterpret_cast<const char*>(v_cache), (size_t)H * ctx * 256, (size_t)ctx * 256, 256u};
+    } else {  // the k / v columns of the qkv rows
+        kv = AttnKv{reinterpret_cast<const char*>(qkv + E), reinterpret_cast<const char*>(qkv + 2 * E), (size_t)P * 3 * E * 4, (size_t)256, (unsigned)(3 * E * 4)};
+    }
+    ZG_REQUIRE((size_t)P * kv.stride_t < ((size_t)1 << 31), ZG_ERR_SHAPE, "attention prefill: rows beyond a 32-bit buffer descriptor");
+    hipLaunchKernelGGL(attn_prefill_pl_kernel, dim3(H, B, ng * max_s), dim3(256), kLds, s, qkv, out, ws, P, E, geo, kv);
     ZG_HIP(hipGetLastError());
     if (max_s > 1) {
         const size_t n = (size_t)B * H * P * 16;

@@ -606,6 +606,79 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                     }
                 });
             });
+        } else if constexpr (KIND == S4_PARTIAL || KIND == S4_QKV) {
+            // fp32 rows of the whole-prompt Linears (N % 64 == 0), every 32 x 32 MFMA tile through the wave's staging image [32][32]
+            // (pitch 144 B) so that a store instruction covers 8 rows x 128 contiguous bytes (straight from the registers it scatters
+            // 32-byte pieces over 32 rows: one L2 request per piece, and the tile's epilogue took 65 k cycles with the cache append).
+            // Write-through: the next kernel reads the rows from every XCD.  A row past M would land in the next slab, so rows are
+            // masked here instead of by the descriptor's end.
+            // S4_QKV: a 32-column tile is half of ONE head of q, k or v (E = 64 H).  q columns go to qkv[M][3E]; k / v go to the
+            // head-major caches [b][h][ctx][64] (src/ops.zig:152-157) — and to qkv as well only when the cache is not fp32 (the
+            // prompt attention reads an fp32 cache directly, prefill.hip).
+            const unsigned sw = lds_base + P::ST_OFF + wave * P::ST_WAVE + (unsigned)l31e * 144u + (unsigned)hhe * 16u;
+            const unsigned sr = lds_base + P::ST_OFF + wave * P::ST_WAVE + (unsigned)(lane_e >> 3) * 144u + (unsigned)(lane_e & 7) * 16u;
+            [[maybe_unused]] float rcp_p = 0.0f;
+            if constexpr (KIND == S4_QKV) rcp_p = 1.0f / (float)qa.P;
+            static_for<4>([&](auto IT) {
+                constexpr int i = decltype(IT)::value;
+                const int mrow = m0 + wr * 128 + i * 32 + (lane_e >> 3);  // the lane's rows of this m-tile: mrow + 8 k
+                [[maybe_unused]] int sb[4], st[4];  // S4_QKV: (sequence, position) of those rows
+                if constexpr (KIND == S4_QKV) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = mrow + 8 * k;
+                        int q = (int)((float)row * rcp_p), r = row - q * qa.P;  // row < 2^24: the estimate is off by at most one
+                        if (r < 0) { --q; r += qa.P; }
+                        if (r >= qa.P) { ++q; r -= qa.P; }
+                        sb[k] = q;
+                        st[k] = r;
+                    }
+                }
+                static_for<NT>([&](auto JT) {
+                    constexpr int j = decltype(JT)::value;
+                    const int gcol = n0 + wc * (P::BN / 2) + j * 32;
+                    asm volatile("s_nop 3" ::: "memory");
+                    float av[16];
+                    acc_read16<16 * (i * NT + j)>(av);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v v4 = {av[4 * g], av[4 * g + 1], av[4 * g + 2], av[4 * g + 3]};
+                        const unsigned sw_l = sw;
+                        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(sw_l), "v"(v4), "i"(g * 32) : "memory");
+                    }
+                    f32x4v o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned sr_l = sr;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o[k]) : "v"(sr_l), "i"(k * 8 * 144) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+                    const int col = gcol + 4 * (lane_e & 7);
+                    bool rows_too = true;
+                    [[maybe_unused]] void* cache = nullptr;
+                    [[maybe_unused]] int e0 = 0;
+                    if constexpr (KIND == S4_QKV) {
+                        if (gcol >= qa.E) {
+                            const int which = gcol >= 2 * qa.E;
+                            e0 = col - (which ? 2 * qa.E : qa.E);
+                            cache = which ? qa.v_cache : qa.k_cache;
+                            rows_too = qa.kv_mode != 0;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = mrow + 8 * k;
+                        const bool ok = row < M && gcol < N;
+                        const unsigned off = (ok && rows_too) ? (unsigned)(sl * M + row) * (unsigned)(ldc * 4) + (unsigned)col * 4u : 0xFFFFFFFFu;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[k]), rc, off, 0, ST_AUX);
+                        if constexpr (KIND == S4_QKV) {
+                            if (cache != nullptr && ok)
+                                kv_cache_store4(qa, cache, (((size_t)sb[k] * qa.H + (e0 >> 6)) * qa.ctx + st[k]) * 64 + (e0 & 63),
+                                                f32x4{o[k][0], o[k][1], o[k][2], o[k][3]});
+                        }
+                    }
+                });
+            });
         } else
         static_for<4>([&](auto IT) {
             constexpr int i = decltype(IT)::value;
@@ -646,21 +719,6 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                         const u32x2 pk = {cvt_pk_bf16(x[2 * g].x, x[2 * g].y), cvt_pk_bf16(x[2 * g + 1].x, x[2 * g + 1].y)};
                         const unsigned st_w_l = st_w;  // (a generic lambda does not capture what only an asm operand names)
                         asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(st_w_l), "v"(pk), "i"(j * 64 + g * 16) : "memory");
-                    }
-                } else if constexpr (KIND == S4_PARTIAL || KIND == S4_QKV) {
-                    // whole-prompt Linears (N % 64 == 0): slab rows / qkv rows, write-through (the next kernel reads them from every
-                    // XCD); a row past M would land in the next slab, so it is masked here instead of by the descriptor's end
-                    const int row = m0 + wr * 128 + i * 32 + l31e;
-                    const unsigned rbase = row < M ? (unsigned)(sl * M + row) * (unsigned)(ldc * 4) : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = gcol + 8 * g + 4 * hhe;
-                        const unsigned off = (col < N && rbase != 0xFFFFFFFFu) ? rbase + (unsigned)col * 4u : 0xFFFFFFFFu;
-                        const f32x4v o = {x[2 * g].x, x[2 * g].y, x[2 * g + 1].x, x[2 * g + 1].y};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off, 0, ST_AUX);
-                        if constexpr (KIND == S4_QKV) {
-                            if (row < M && col < N) qkv_cache_store(qa, row, col, f32x4{o[0], o[1], o[2], o[3]});
-                        }
                     }
                 } else {
 #pragma unroll

@@ -35,11 +35,6 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ bf16_t cvt_bf16(float x) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return (bf16_t)r;
-}
 // four consecutive values -> 8 B into each of the kSplit planes (plane stride `plane` elements); the split
 // is exact: x = hi + mid + lo (zg_common.h split3_pk)
 __device__ __forceinline__ void store_split4(bf16_t* dst, size_t plane, f32x4 v) {
@@ -829,8 +824,15 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 // N = n_embed Linears (residual adds) get there by slicing K over the tile list, their partial slabs summed by the reduce
 // kernels above in fixed order (which also apply bias, residual and the LayerNorm + split that follows).  Returns the slice
 // count, 0 = the 128-row kernels of this file take the launch.
+static int g_force_kernel = 0, g_force_slices = 0;  // zg_debug_prefill_linear: 1 = gemm_s4, 2 = the 128-row kernels; K slices
+void prefill_force_route(int kernel, int slices) {
+    g_force_kernel = kernel;
+    g_force_slices = slices;
+}
 static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws) {
-    const int min_tiles = getenv("ZGPT2_PF_S4_TILES") ? atoi(getenv("ZGPT2_PF_S4_TILES")) : (1 << 30);  // (off until its epilogues beat the 128-row kernels: profiles/round5 notes)
+    int min_tiles = getenv("ZGPT2_PF_S4_TILES") ? atoi(getenv("ZGPT2_PF_S4_TILES")) : 192;  // tiles of 256 x 192 (x K slices) from which the persistent kernel takes the launch: three quarters of the CUs
+    if (g_force_kernel == 1) min_tiles = 1;
+    if (g_force_kernel == 2) return 0;
     const int kpp = K / 64;
     if (K % 64 != 0 || kpp < 2 || kSplit * K >= 65536) return 0;
     const long tiles = (long)((M + 255) / 256) * ((N + 191) / 192);
@@ -838,7 +840,7 @@ static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws
     if (!have_ws) return 0;
     for (int n_sl = 1; n_sl <= kpp / 2; ++n_sl) {
         if (kpp % n_sl != 0 || (size_t)n_sl * M * N > ws_floats) continue;
-        if (tiles * n_sl >= min_tiles) return n_sl;
+        if (g_force_slices > 0 ? n_sl == g_force_slices : tiles * n_sl >= min_tiles) return n_sl;
     }
     return 0;
 }

@@ -67,11 +67,14 @@ __device__ __forceinline__ void b24_store(void* cache, size_t lo_off, size_t ele
     reinterpret_cast<uint8_t*>(cache)[lo_off + elem] = (uint8_t)r;
 }
 
-// Two fp32 values -> packed bf16 pair (round to nearest even), one gfx950 instruction; lo half = a.
+// Two fp32 values -> packed bf16 pair (round to nearest even), one gfx950 instruction (v_cvt_pk_bf16_f32); lo half = a.
+// Through the compiler's own conversion, NOT an asm statement: the hazard recognizer pads nothing around inline asm, and a
+// packed pair that an MFMA reads as an operand right behind the conversion was read half-written — alternating groups of four
+// B-operand columns kept the old register contents (the pipelined prompt attention, round 5: tools/dbg_attn_all.py).
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
 // Exact three-term bf16 split of two fp32 values: x = hi + mid + lo (24 = 8 + 8 + 8 mantissa bits; every
