@@ -286,11 +286,26 @@ def other_config(lib, stream, model_name, ppg, gens, seed, kv_b24=False):
             "dominant_class": {k: dom[k] for k in ("class", "kernel_symbol", "avg_launch_us", "avg_launch_us_layers_walked", "algorithmic_bytes_per_launch",
                                                    "GBps", "frac_of_8TBps", "share_of_token_time")},
             "lm_head": {k: lm[k] for k in ("kernel_symbol", "avg_launch_us", "GBps", "frac_of_8TBps")},
-            "prefill": {"prompt_tokens": ctx - 1, "prompts": ppg, "ms": round(pf_ms, 3), "prompt_tokens_per_s": round(ppg * (ctx - 1) / pf_ms * 1e3, 1)},
+            "prefill": {"prompt_tokens": ctx - 1, "prompts": ppg, "ms": round(pf_ms, 3), "prompt_tokens_per_s": round(ppg * (ctx - 1) / pf_ms * 1e3, 1),
+                        **prefill_flops(cfg, ppg, ctx - 1, pf_ms)},
+            "checked": False,  # timed only: the same shapes are held to the oracle by pytest (tests/test_full_configs_gpu.py, test_prefill_gpu.py)
             "data": "synthetic (torch.randn on the GPU, bf16-representable)", "first_tokens": [int(t) for t in ids[0, :4]],
         }
     finally:
         model.close()
+
+
+def prefill_flops(cfg, prompts, n, ms, planes=3):
+    """Matrix-core work of one whole-prompt pass: the useful Linear FLOPs (2 M K N each), and what the MFMAs execute — `planes`
+    bf16 plane products per Linear (exact split of the fp32 activations), six per attention product (both operands split),
+    causal attention counted over the 32 x 32 tiles it visits."""
+    E, L, H = cfg.n_embed, cfg.n_layer, cfg.n_heads
+    lin = 2.0 * prompts * n * 12 * E * E * L
+    nqb = (n + 31) // 32
+    tiles = nqb * (nqb + 1) // 2
+    attn = 2.0 * 2 * tiles * 32 * 32 * 64 * H * prompts * L  # S = q k^T and P v per visited tile
+    return {"linear_tflops_useful": round(lin / ms / 1e9, 1), "mfma_tflops": round((planes * lin + 6 * attn) / ms / 1e9, 1),
+            "mfma_frac_of_2.5PF": round((planes * lin + 6 * attn) / ms / 1e9 / 2500.0, 4)}
 
 
 def main():
@@ -337,16 +352,33 @@ def main():
     if rank == 0:
         weights = synth.make_weights(cfg, seed=a.seed, bf16=not a.weights_f32)
         model.load_weights(weights)
+    # The one collective of the multi-GPU case goes through the library's own RCCL path (zg_dist_* / zg_gpt_broadcast_weights,
+    # include/zgpt2.h): rank 0 makes the communicator id, torch.distributed only ships its 128 bytes.  With one rank the same calls
+    # run on a one-rank communicator, so the line always carries the device time of the broadcast.
+    import ctypes as C
+
     bcast_ms = None
-    if use_dist:
-        ptr, nbytes = model.weight_arena()
-        arena = torch.as_tensor(_DevMem(ptr, nbytes), device=torch.device("cuda", local_rank))
+    bcast_note = None
+    try:
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(lib.zg_dist_unique_id(uid, 128))
+        if use_dist:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        _lib.check(lib.zg_dist_init(uid, 128, rank, world))
         torch.cuda.synchronize()
-        dist.barrier()
-        tb = time.perf_counter()
-        shard.broadcast_weights(arena, dist, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - tb) * 1e3
+        if use_dist:
+            dist.barrier()
+        ms = C.c_float(0.0)
+        _lib.check(lib.zg_gpt_broadcast_weights(model.h, 0, C.byref(ms)))
+        bcast_ms = float(ms.value)
+        _lib.check(lib.zg_dist_finalize())
+    except _lib.ZgError as e:
+        if world > 1:
+            raise
+        bcast_note = str(e)  # (a one-GPU box without librccl: nothing to broadcast to)
     setup_s = time.perf_counter() - t0
 
     # ---- prompts: one token each, distinct per global prompt index
@@ -447,12 +479,12 @@ def main():
             p_ms = time_prefill(model)
             prefill = {"prompt_tokens": n_p, "prompts": ppg, "ms": round(p_ms, 3),
                        "prompt_tokens_per_s": round(ppg * n_p / p_ms * 1e3, 1),
-                       "linear_tflops_useful": round(lin_flops / p_ms / 1e9, 1),
+                       **prefill_flops(cfg, ppg, n_p, p_ms),
                        "vs_token_at_a_time": round((1e3 * elapsed / a.steps) * n_p / ctx / p_ms, 1),
                        "how": "synchronous zg_gpt_prefill calls (host wall clock, 5 repetitions after 3 warm-ups); "
                               + ("fp32 weights: both GEMM operands as exact bf16 plane triples, the six plane products as three "
                                  "passes of one launch of the 128-row prompt GEMM per Linear" if a.weights_f32 else
-                                 "activations split exactly 3-way into bf16 for the MFMA GEMMs") + ", fp32-MFMA causal attention"}
+                                 "activations split exactly 3-way into bf16 for the MFMA GEMMs") + ", causal attention on the bf16 matrix cores with exact three-plane splits of q, k, v and the probabilities (six plane products per matrix product)"}
             if not a.weights_f32:  # the two-plane mode (inside north_star's 1e-3, outside the tests' near-zero floor)
                 m2 = gpt.GPT(cfg, batch=ppg, use_graph=False, kv_f16=a.kv_f16, kv_b24=a.kv_b24, prefill_planes=2)
                 m2.load_weights(weights)
@@ -531,7 +563,8 @@ def main():
         "other_configs": others,
         "device_time_s": round(dev_s, 4),
         "setup_s": round(setup_s, 2),
-        "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
+        "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 3),
+        "weight_broadcast": bcast_note or "zg_gpt_broadcast_weights: one ncclBroadcast of the arena's weight region on the library's stream (device time, HIP events)",
         "first_tokens": [int(t) for t in ids[0, :8]],
     }
     if not a.no_cpu_baseline and world == 1:

@@ -150,21 +150,3 @@ def test_gemm_k_beyond_the_packed_arguments_runs_on_the_eight_wave_kernel(zg):
     t = torch.zeros(128 * 16384, dtype=torch.int16, device="cuda")
     c = torch.zeros(128 * 128, dtype=torch.float32, device="cuda")
     assert zg.zg_gemm_bf16_nt(t.data_ptr(), t.data_ptr(), None, c.data_ptr(), 128, 126, 16384, 0, 0) == -5
-
-
-@pytest.mark.parametrize("m,n,k,wgs", [(256, 192, 128, 0), (1100, 776, 320, 3), (2048, 1536, 768, 5)])
-@pytest.mark.parametrize("gelu", [False, True])
-def test_gemm_overlapped_epilogue_experiment_equals_the_four_wave_kernel(zg, m, n, k, wgs, gelu, monkeypatch):
-    """gemm_ov_kernel (ZGPT2_GEMM_KERNEL=ov; the epilogue of a tile under the next tile's main loop, DESIGN 8.1: measured
-    slower than gemm_s4 at two tiles per workgroup and not dispatched by default) computes the same fp32 values in the same
-    order: its bf16 output must be bitwise that of gemm_s4, also with several tiles per workgroup."""
-    if wgs:
-        monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
-    a = synth.fill_normal(41, m * k, 0.0, 1.0, bf16=True).reshape(m, k)
-    b = synth.fill_normal(42, n * k, 0.0, 0.05, bf16=True).reshape(n, k)
-    bias = synth.fill_normal(43, n, 0.0, 0.5)
-    monkeypatch.setenv("ZGPT2_GEMM_KERNEL", "s4")
-    ref = run_gemm(zg, a, b, bias, gelu, out_bf16=True)
-    monkeypatch.setenv("ZGPT2_GEMM_KERNEL", "ov")
-    got = run_gemm(zg, a, b, bias, gelu, out_bf16=True)
-    assert np.array_equal(ref, got)

@@ -26,7 +26,7 @@
 
 #include <type_traits>
 
-#include "zg_kernels.h"
+#include "gemm_ov.h"
 
 namespace zg {
 

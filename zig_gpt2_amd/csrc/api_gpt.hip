@@ -70,19 +70,6 @@ struct zg_gpt {
     size_t sk_tag_bytes, part_tag_bytes;
     size_t epochs_since_clear;  // steps enqueued since the tagged words were last zeroed (note_steps)
     bool tags_on;
-    // Two-stream decode of ONE sequence ("dual"): the kernels of a step are dealt to two hipGraphs on two streams — A: embed,
-    // then per Block ln_1 + c_attn, attention, merge + c_proj (the last Block whole, and lm_head); B: ln_2 + c_fc and mlp c_proj
-    // of every Block but the last — and the residual stream crosses between them as (value, tag) granules xg (GemvArgs.xg): the
-    // kernel on the other stream is resident, its weights in flight, while its producer still runs, instead of starting behind
-    // a kernel boundary (tools/microbench/two_graph_probe.hip: 4.31 -> 3.28 us per dependent 768 x 768 stage).
-    // (A third stream — mlp c_proj on its own, gelu(c_fc) crossing as 4 E granules — was measured slower, 218.6-220.0 against
-    // 213.2-214.7 us per token, and removed: DESIGN 8.3.)
-    bool dual_on;
-    unsigned long long* xg;   // [E] granules
-    unsigned* epoch2;         // step counters of the graphs: [0] A (advanced by the embed kernel), [64] B (by a bump kernel)
-    hipStream_t s2;
-    hipEvent_t ev_fork, ev_join;
-    std::vector<hipGraphExec_t> graphs_b, graphs_kb;  // the B parts of graphs / graphs_k
     // LayerNorm statistics of x by 16-column tile, written by the producers of x (GemvArgs.st_out / st_in)
     float* xst;
     bool st_on;
@@ -192,8 +179,6 @@ void carve(zg_gpt* g, char* base) {
     g->attn_cnt = (int*)P(8 * c.n_heads * 4);
     g->epoch = (unsigned*)P(256);
     g->xst = (float*)P(((E + 15) / 16) * 8 * 2 * 4);
-    g->xg = (unsigned long long*)P(E * 8);
-    g->epoch2 = (unsigned*)P(1024);
     g->sk_tag_bytes = ((E + 15) / 16) * 4 * 128 * 8;
     g->part_tag_bytes = 8 * c.n_heads * g->max_splits * kPartStride * 8;
     g->sk_tag = (unsigned long long*)P(g->sk_tag_bytes);
@@ -372,40 +357,20 @@ int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
 // layer, so that consecutive launches of the chain never find each other's tags.
 int env_int(const char* name, int dflt);
 
-// part (two-stream decode, zg_gpt.dual_on): -1 = the whole step on one stream, x as plain fp32 (also every measurement
-// path); 0 = the A half; 1 = the B half.  In the halves x crosses the streams as granules: writer ids 1 (embed),
-// 2 + 2 l (merge + c_proj of Block l), 3 + 2 l (mlp c_proj of Block l); the last Block runs whole on A with plain x.
 int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1, size_t only_layer = 0,
-                 std::vector<PfJob>* rec = nullptr, int salt = -1, int part = -1) {
-    const size_t E = g->cfg.n_embed, L = g->cfg.n_layer;
+                 std::vector<PfJob>* rec = nullptr, int salt = -1) {
+    const size_t E = g->cfg.n_embed;
     auto launch_id = [&](size_t l, int k) { return (unsigned)(salt >= 0 ? 1 + (2 * salt + k) % 254 : 2 * (int)l + 1 + k); };
-    const bool dual = part >= 0;
-    auto in_part = [&](size_t l, int k) {  // does kernel class k of Block l belong to this call?
-        if (!dual) return true;
-        const int owner = ((k == 4 || k == 5) && l + 1 < L) ? 1 : 0;
-        return owner == part;
-    };
-    auto xg_common = [&](GemvArgs& a) {
-        a.xg = g->xg;
-        a.epoch2 = g->epoch2 + 64 * part;
-        a.fault = g->fault;
-        a.spin_limit = g->spin_limit;
-    };
     ZG_TRY(prof_mark(prof, -1, s));
     if (rec) rec->push_back(PfJob{});
-    else if (part >= 1) ZG_TRY(launch_epoch_bump(g->epoch2 + 64 * part, s));  // the B / C parts count the same steps as A
     else if (only < 0 || only == 0) {
         EmbedArgs e = embed_args(g, only == 0 ? 3 : 0);  // main.zig:179-183
-        if (dual) {
-            e.xg = g->xg;
-            e.epoch2 = g->epoch2;
-        }
         ZG_TRY(launch_embed_step(e, s));
     }
     ZG_TRY(prof_mark(prof, 0, s));
     for (size_t l = (only < 0 ? 0 : only_layer); l < (only < 0 ? g->cfg.n_layer : only_layer + 1); ++l) {
         const zg_layer& y = g->layers[l];
-        if ((only < 0 || only == 1) && in_part(l, 1)) {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
+        if (only < 0 || only == 1) {   // ln_1 + c_attn + split_qkv + cache append: main.zig:121-123, ops.zig:143-157
             GemvArgs a = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * E, E, t_hi);
             a.prologue = PRO_LAYERNORM;
             a.x = g->x;
@@ -420,16 +385,11 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
             a.q = g->q;
             a.k_cache = y.k_cache;
             a.v_cache = y.v_cache;
-            if (dual) {  // x from the embed kernel (same stream: complete) or from the B half's mlp c_proj of the Block before
-                xg_common(a);
-                a.xin_id = l == 0 ? 0u : (unsigned)(3 + 2 * (l - 1));
-                a.xout_id = (unsigned)env_int("ZGPT2_DUAL_SLEEP", 4);
-            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 1));
             ZG_TRY(prof_mark(prof, 1, s));
         }
-        if ((only < 0 || only == 2) && in_part(l, 2)) {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
+        if (only < 0 || only == 2) {   // scaled_dot_product_attention over the cache: ops.zig:160 -> :249-307
             AttnArgs a{};
             a.q = g->q;
             a.k = y.k_cache;
@@ -473,7 +433,7 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 ZG_TRY(launch_attn_decode(a, s));
             ZG_TRY(prof_mark(prof, 2, s));
         }
-        if ((only < 0 || only == 3) && in_part(l, 3)) {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
+        if (only < 0 || only == 3) {   // merge heads + attn c_proj + residual: ops.zig:171-172, main.zig:136-139
             GemvArgs a = base_gemv(g, y.c_proj_w, y.c_proj_b, E, E, t_hi);
             a.prologue = PRO_ATTN_MERGE;
             a.part = g->part;
@@ -489,16 +449,11 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 a.pl_g = y.ln_2_g;
                 a.st_out = g->st_on ? g->xst : nullptr;
             }
-            if (dual) {  // residual from the granules (complete: this Block's c_attn saw every tag); output to the B half
-                xg_common(a);
-                a.xg_resid = 1;
-                a.xout_id = l + 1 < L ? (unsigned)(2 + 2 * l) : 0u;  // (the last Block continues on this stream: plain x)
-            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 3));
             ZG_TRY(prof_mark(prof, 3, s));
         }
-        if ((only < 0 || only == 4) && in_part(l, 4)) {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
+        if (only < 0 || only == 4) {   // ln_2 + c_fc + gelu: main.zig:140, :79-80
             GemvArgs a = base_gemv(g, y.c_fc_w, y.c_fc_b, 4 * E, E, t_hi);
             a.prologue = PRO_LAYERNORM;
             a.x = g->x;
@@ -516,16 +471,11 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                 a.pl_out = g->hp;
                 a.y = nullptr;
             }
-            if (part == 1) {  // x from the A part's merge + c_proj of this Block
-                xg_common(a);
-                a.xin_id = (unsigned)(2 + 2 * l);
-                a.xout_id = (unsigned)env_int("ZGPT2_DUAL_SLEEP", 4);
-            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 4));
             ZG_TRY(prof_mark(prof, 4, s));
         }
-        if ((only < 0 || only == 5) && in_part(l, 5)) {   // mlp c_proj + residual: main.zig:81, :142-145
+        if (only < 0 || only == 5) {   // mlp c_proj + residual: main.zig:81, :142-145
             GemvArgs a = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, E, 4 * E, t_hi);
             a.prologue = PRO_NONE;
             a.x = g->h4;
@@ -550,17 +500,12 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
                     a.st_out = g->st_on ? g->xst : nullptr;
                 }
             }
-            if (part >= 1) {  // input from the B part's c_fc; residual from the granules (that c_fc saw every tag); output to A
-                xg_common(a);
-                a.xg_resid = 1;
-                a.xout_id = (unsigned)(3 + 2 * l);
-            }
             const int grid = gemv_plan(a, g->wt);
             ZG_TRY(emit_gemv(g, a, grid, s, rec, 5));
             ZG_TRY(prof_mark(prof, 5, s));
         }
     }
-    if (with_logits && (only < 0 || only == 6) && part <= 0) {
+    if (with_logits && (only < 0 || only == 6)) {
         ZG_TRY(enqueue_lm_head(g, s, rec));
         ZG_TRY(prof_mark(prof, 6, s));
     }
@@ -592,9 +537,8 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_attn_p : (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
                                    g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
-        if (getenv("ZGPT2_PF_ATTN_OLD")) ZG_TRY(launch_attn_prefill_f32(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, s));
-        else  // (an fp32 cache is read directly: the c_attn epilogue then need not store the k / v columns of qkv)
-            ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, g->pf_ws, g->pf_ws_floats, g->kv_mode == 0 ? (const float*)y.k_cache : nullptr,
+        // (an fp32 cache is read directly: the c_attn epilogue then need not store the k / v columns of qkv)
+        ZG_TRY(launch_attn_prefill(g->pf_qkv, g->pf_a, B, (int)P, iE, (int)H, g->pf_ws, g->pf_ws_floats, g->kv_mode == 0 ? (const float*)y.k_cache : nullptr,
                                        g->kv_mode == 0 ? (const float*)y.v_cache : nullptr, (int)C, s));
         const PrefillLn ln2{y.ln_2_g, y.ln_2_b, 1e-5f, g->pf_a};
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_proj_p : (const bf16_t*)y.c_proj_w, y.c_proj_b, g->pf_x, M, iE, iE, iE, PF_RESID, g->pf_ws,
@@ -614,19 +558,10 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
 // call).  The word lives in pinned host memory the kernels store to directly: reading it costs no copy and no second
 // synchronisation.  PRECONDITION: the stream has been drained since the steps in question.
 int check_fault(zg_gpt* g) {
-    if (!g->tags_on && !g->dual_on) return ZG_OK;
+    if (!g->tags_on) return ZG_OK;
     volatile unsigned* f = g->fault;
     if (*f == 0) return ZG_OK;
     *f = 0;
-    if (g->dual_on && getenv("ZGPT2_DUAL_DEBUG")) {
-        unsigned ep[128];
-        unsigned long long xs[8];
-        (void)hipMemcpy(ep, g->epoch2, 512, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(xs, g->xg, 64, hipMemcpyDeviceToHost);
-        fprintf(stderr, "dual debug: epochA %u epochB %u; xg tags:", ep[0], ep[64]);
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %x", (unsigned)(xs[i] >> 32));
-        fprintf(stderr, "\n");
-    }
     set_error("a tagged hand-over of the decode step timed out (a workgroup waited %u polls for its writers): results discarded", g->spin_limit);
     return ZG_ERR_HIP;
 }
@@ -662,9 +597,6 @@ int setup_prefetcher(zg_gpt* g) {
     const bool small = g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
     const int want = env_int("ZGPT2_PREFETCH", small ? 1 : 0);
     if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || ctx().stream == nullptr) return ZG_OK;
-    // the two-stream decode overlaps a kernel's weight fetch with its predecessor itself (and its launches do not pass the
-    // one progress counter the prefetcher follows in order)
-    if (g->dual_on) return ZG_OK;  // (both together: 227-242 against 213 us per token)
     if (g->pf_njobs > 255) return ZG_OK;  // the progress word counts launches in 8 bits (n_layer >= 51): no prefetcher, not an error
     std::vector<PfJob> jobs;
     ZG_TRY(enqueue_step(g, true, (int)g->cfg.context_size, nullptr, nullptr, -1, 0, &jobs));
@@ -696,8 +628,6 @@ void drop_prefetcher(zg_gpt* g) {
 // starts once the decode stream reaches this point.  pf_stop() goes behind the last step.
 int pf_start(zg_gpt* g, size_t last_T, hipStream_t s) {
     if (!g->pf_on || s == nullptr) return ZG_OK;
-    const int mode = env_int("ZGPT2_PF_MODE", 0);  // measurement: 1 = follow the chain but fetch nothing, 2 = count only
-    if (mode == 2) return ZG_OK;
     if (g->pf_ran) {  // how did the previous one leave?  (the decode stream was synchronised by the caller)
         ZG_HIP(hipStreamSynchronize(g->pf_stream));
         unsigned why[8];
@@ -724,18 +654,15 @@ int pf_start(zg_gpt* g, size_t last_T, hipStream_t s) {
     a.ctl = g->pf_ctl;
     a.jobs = g->pf_jobs;
     a.njobs = g->pf_njobs;
-    a.lead = env_int("ZGPT2_PF_LEAD", 2);
-    a.nsub = env_int("ZGPT2_PF_NSUB", 12);
+    // the measured optimum of the round-2 / round-3 sweeps (profiles/NOTEBOOK.md), constants since round 5
+    a.lead = 2;    // launches ahead of the running one
+    a.nsub = 12;   // prefetcher workgroups per XCD
     a.max_T = (int)last_T;
-    a.idle_limit = (unsigned)env_int("ZGPT2_PF_IDLE", 100000);  // polls without progress (~0.1 s) before it gives up
-    a.sleep = (unsigned)env_int("ZGPT2_PF_SLEEP", 1);
-    a.cls_mask = (unsigned)env_int("ZGPT2_PF_CLASSES", 0x3e);  // lm_head's head start measured a net loss
-    a.line_shift = 7;  // one touch per 128-byte line
-    a.cap_bytes = (unsigned)env_int("ZGPT2_PF_CAP_KB", 0) << 10;
-    if (mode == 1) a.max_T = 0;
-    if (a.lead < 1) a.lead = 1;
-    if (a.nsub < 1) a.nsub = 1;
-    if (a.nsub > 32) a.nsub = 32;
+    a.idle_limit = (unsigned)env_int("ZGPT2_PF_IDLE", 100000);  // polls without progress (~0.1 s) before it gives up (0: the test of that exit)
+    a.sleep = 1;
+    a.cls_mask = 0x3e;  // every class but lm_head (its head start measured a net loss)
+    a.line_shift = 7;   // one touch per 128-byte line
+    a.cap_bytes = 0;
     g->pf_ran = true;
     return launch_prefetcher(a, g->pf_stream);
 }
@@ -749,7 +676,7 @@ int pf_stop(zg_gpt* g, hipStream_t s) {
 size_t prefill_min() { return 4; }  // shorter prompts go through the decode chain (measured: the whole-prompt pass pays from 4 tokens up)
 
 void drop_graphs(zg_gpt* g) {
-    for (auto* v : {&g->graphs, &g->graphs_k, &g->graphs_b, &g->graphs_kb})
+    for (auto* v : {&g->graphs, &g->graphs_k})
         for (auto& e : *v)
             if (e) {
                 (void)hipGraphExecDestroy(e);
@@ -759,12 +686,12 @@ void drop_graphs(zg_gpt* g) {
 
 // Run one decode step at sequence length seq_len: replay the graph of its bucket (capturing it on
 // first use), or launch eagerly when graphs are disabled / the stream cannot be captured.
-// n_steps consecutive steps (part as enqueue_step) captured on stream cs into *out
-int capture_steps(zg_gpt* g, hipGraphExec_t* out, bool with_logits, int t_hi, size_t n_steps, int part, hipStream_t cs) {
+// n_steps consecutive steps captured on stream cs into *out
+int capture_steps(zg_gpt* g, hipGraphExec_t* out, bool with_logits, int t_hi, size_t n_steps, hipStream_t cs) {
     hipGraph_t graph = nullptr;
     ZG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int st = ZG_OK;
-    for (size_t i = 0; i < n_steps && st == ZG_OK; ++i) st = enqueue_step(g, with_logits, t_hi, cs, nullptr, -1, 0, nullptr, -1, part);
+    for (size_t i = 0; i < n_steps && st == ZG_OK; ++i) st = enqueue_step(g, with_logits, t_hi, cs);
     hipError_t e = hipStreamEndCapture(cs, &graph);
     if (st != ZG_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -780,43 +707,18 @@ int capture_bucket(zg_gpt* g, size_t idx, hipStream_t s) {
     const size_t seq_len = (idx / 2 + 1) * 64;  // any length of the bucket: only its upper bound is baked in
     const bool with_logits = idx & 1;
     if (g->graphs.size() <= idx) g->graphs.resize(idx + 1, nullptr);
-    if (g->graphs_b.size() <= idx) g->graphs_b.resize(idx + 1, nullptr);
     if (g->graphs[idx]) return ZG_OK;
     const int t_hi = bucket_t_hi(g, seq_len);
-    if (g->dual_on) ZG_TRY(capture_steps(g, &g->graphs_b[idx], with_logits, t_hi, 1, 1, g->s2));
-    return capture_steps(g, &g->graphs[idx], with_logits, t_hi, 1, g->dual_on ? 0 : -1, s);
+    return capture_steps(g, &g->graphs[idx], with_logits, t_hi, 1, s);
 }
 
 // graph_steps consecutive decode steps (all with lm_head, all in 64-position bucket b) as ONE graph: the position lives
 // in device memory, so the same kernels simply repeat; saves the gap between graph launches in the generate loop.
 int capture_multi(zg_gpt* g, size_t b, hipStream_t s) {
     if (g->graphs_k.size() <= b) g->graphs_k.resize(b + 1, nullptr);
-    if (g->graphs_kb.size() <= b) g->graphs_kb.resize(b + 1, nullptr);
     if (g->graphs_k[b]) return ZG_OK;
     const int t_hi = bucket_t_hi(g, (b + 1) * 64);
-    if (g->dual_on) ZG_TRY(capture_steps(g, &g->graphs_kb[b], true, t_hi, g->graph_steps, 1, g->s2));
-    return capture_steps(g, &g->graphs_k[b], true, t_hi, g->graph_steps, g->dual_on ? 0 : -1, s);
-}
-
-// Two-stream decode: the B stream starts behind everything enqueued on s so far (LayerNorm folds, prefill), and s continues
-// behind the B half of the steps launched since — so that draining s drains both.
-int dual_fork(zg_gpt* g, hipStream_t s) {
-    if (!g->dual_on) return ZG_OK;
-    ZG_HIP(hipEventRecord(g->ev_fork, s));
-    ZG_HIP(hipStreamWaitEvent(g->s2, g->ev_fork, 0));
-    return ZG_OK;
-}
-int dual_join(zg_gpt* g, hipStream_t s) {
-    if (!g->dual_on) return ZG_OK;
-    ZG_HIP(hipEventRecord(g->ev_join, g->s2));
-    ZG_HIP(hipStreamWaitEvent(s, g->ev_join, 0));
-    return ZG_OK;
-}
-// launch a captured step (or steps) on s — and its B half on the second stream
-int launch_graphs(zg_gpt* g, hipGraphExec_t a, hipGraphExec_t b, hipStream_t s) {
-    ZG_HIP(hipGraphLaunch(a, s));
-    if (g->dual_on) ZG_HIP(hipGraphLaunch(b, g->s2));
-    return ZG_OK;
+    return capture_steps(g, &g->graphs_k[b], true, t_hi, g->graph_steps, s);
 }
 
 // All decode graphs of a handle (two per 64-position bucket: with / without lm_head) for stream s.  Called from
@@ -844,7 +746,8 @@ int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
     if (g->graph_stream != s) ZG_TRY(capture_all(g, s));  // the caller switched streams after zg_gpt_create
     const size_t idx = ((seq_len + 63) / 64 - 1) * 2 + (with_logits ? 1 : 0);
     ZG_TRY(capture_bucket(g, idx, s));  // no-op: captured at create
-    return launch_graphs(g, g->graphs[idx], g->graphs_b[idx], s);
+    ZG_HIP(hipGraphLaunch(g->graphs[idx], s));
+    return ZG_OK;
 }
 
 int upload_f32(const float* src, size_t n, void* dst, bool as_bf16, hipStream_t s) {
@@ -945,50 +848,6 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     }
     g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
     g->spin_limit = (unsigned)env_int("ZGPT2_TAG_SPIN_LIMIT", 1 << 20);
-    // Two-stream decode: one sequence, bf16 weights, graphs, at least two Blocks, and every kernel on the x edges one that
-    // knows granules (K-split kernels: n_embed <= 1024 for the head-merging c_proj, 4 n_embed >= 2048 for mlp c_proj).
-    // n_embed <= 1024 is also the OCCUPANCY bound: a consumer is launched before its producer and polls from every workgroup
-    // it has, so consumer + producer must fit the chip together — at GPT-2 XL ln_1 + c_attn alone is 600 workgroups of the
-    // ~1024 that fit, and the producers queue behind the pollers until these give up (measured: every step timed out).
-    g->dual_on = false;
-    g->s2 = nullptr;
-    g->ev_fork = g->ev_join = nullptr;
-    if (batch == 1 && g->wt == WT_BF16 && c.n_layer >= 2 && c.n_layer <= 120 && !(flags & ZG_GPT_NO_GRAPH) && ctx().stream != nullptr &&
-        env_int("ZGPT2_DUAL", 0)) {  // measured at parity with the side-stream prefetcher: opt-in
-        const zg_layer& y = g->layers[0];
-        const int t_top = (int)c.context_size;
-        GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, t_top);
-        a1.prologue = PRO_LAYERNORM;
-        a1.ln_c2 = y.c_attn_c2;
-        a1.ln_c3 = y.c_attn_c3;
-        a1.epilogue = EPI_QKV;
-        GemvArgs a4 = a1;
-        a4.N = (int)(4 * c.n_embed);
-        a4.ln_c2 = y.c_fc_c2;
-        a4.ln_c3 = y.c_fc_c3;
-        a4.epilogue = EPI_GELU;
-        GemvArgs a3 = base_gemv(g, y.c_proj_w, y.c_proj_b, c.n_embed, c.n_embed, t_top);
-        a3.prologue = PRO_ATTN_MERGE;
-        a3.epilogue = EPI_RESIDUAL;
-        GemvArgs a5 = base_gemv(g, y.mlp_proj_w, y.mlp_proj_b, c.n_embed, 4 * c.n_embed, t_top);
-        a5.prologue = PRO_NONE;
-        a5.epilogue = EPI_RESIDUAL;
-        g->dual_on = gemv_xg_ok(a1, g->wt) && gemv_xg_ok(a3, g->wt) && gemv_xg_ok(a4, g->wt) && gemv_xg_ok(a5, g->wt);
-    }
-    if (g->dual_on) {
-        // The two streams must sit on different HARDWARE queues: two HIP streams that share one (the runtime deals its few
-        // queues round robin) execute in submission order, and a polling kernel queued in front of its producer never sees it
-        // run.  Streams of different priorities never share a queue: B runs above the caller's stream.
-        int prio_lo = 0, prio_hi = 0;
-        hipError_t he2 = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (he2 == hipSuccess) he2 = hipStreamCreateWithPriority(&g->s2, hipStreamNonBlocking, prio_hi);
-        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
-        if (he2 == hipSuccess) he2 = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
-        if (he2 == hipSuccess) he2 = hipMemsetAsync(g->epoch2, 0, 1024, ctx().stream);
-        if (he2 == hipSuccess) he2 = hipMemsetAsync(g->xg, 0, c.n_embed * 8, ctx().stream);
-        if (he2 == hipSuccess) he2 = hipStreamSynchronize(ctx().stream);
-        if (he2 != hipSuccess) g->dual_on = false;  // (the single-stream step is always available)
-    }
     g->st_on = false;
     if (g->pl_on && !env_int("ZGPT2_NO_TILE_STATS", 0) && c.n_embed % 16 == 0 && c.n_embed / 16 <= 128) {
         // every producer and consumer of x must be the four-wave kernel
@@ -1061,12 +920,8 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
 int zg_gpt_destroy(zg_gpt* g) {
     if (!g) return ZG_OK;
     (void)hipStreamSynchronize(ctx().stream);
-    if (g->s2) (void)hipStreamSynchronize(g->s2);
     drop_prefetcher(g);
     drop_graphs(g);
-    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    if (g->s2) (void)hipStreamDestroy(g->s2);
     (void)hipFree(g->arena);
     (void)hipHostFree(g->h_ctrl);
     (void)hipHostFree(g->h_ints);
@@ -1205,9 +1060,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
     ZG_TRY(note_steps(g, 1, s));
     ZG_TRY(ensure_ln_folded(g, s));
-    ZG_TRY(dual_fork(g, s));
     ZG_TRY(run_step(g, compute_logits != 0, seq_len, s));
-    ZG_TRY(dual_join(g, s));
     if (logits_out) {
         ZG_HIP(hipMemcpyAsync(logits_out, g->logits, g->batch * V * sizeof(float),
                               is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -1349,7 +1202,6 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_TRY(ensure_ln_folded(g, s));
     if (!(g->flags & ZG_GPT_NO_GRAPH) && s != nullptr && g->graph_stream != s) ZG_TRY(capture_all(g, s));  // before the prefetcher starts its idle clock
     ZG_TRY(note_steps(g, n_steps, s));
-    ZG_TRY(dual_fork(g, s));
     ZG_TRY(pf_start(g, n_steps, s));
     int rs = ZG_OK;
     const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;
@@ -1366,7 +1218,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
             if (g->graph_stream != s) rs = capture_all(g, s);
             const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
             if (rs == ZG_OK) rs = capture_multi(g, b, s);
-            if (rs == ZG_OK) rs = launch_graphs(g, g->graphs_k[b], g->graphs_kb[b], s);
+            if (rs == ZG_OK && hipGraphLaunch(g->graphs_k[b], s) != hipSuccess) rs = ZG_ERR_HIP;
             st += K;
         } else {
             rs = run_step(g, st >= min_prompt, st + 1, s);
@@ -1374,7 +1226,6 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
         }
     }
     ZG_TRY(pf_stop(g, s));  // also after a failed launch: the prefetcher must not wait for steps that never come
-    ZG_TRY(dual_join(g, s));
     ZG_TRY(rs);
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
     g->steps_enqueued = n_steps;

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         }
         {   // the argument-block fields used behind the partial-maxima loads (zg_common.h ZG_PIN)
             ZG_PIN(a.forced); ZG_PIN(a.wte); ZG_PIN(a.wpe); ZG_PIN(a.weight_type); ZG_PIN(a.n_embed); ZG_PIN(a.cur_token); ZG_PIN(a.out_tokens);
-            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.xg); ZG_PIN(a.epoch2); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only); ZG_PIN(a.st_out);
+            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only); ZG_PIN(a.st_out);
         }
         if (b == 0 && a.progress != nullptr && a.finish_only == 0 && lane == 0) {
             // a step at sequence length s + 1 starts; block 0 of every launch of this queue lands on the XCD this block is on
@@ -251,15 +251,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
             const f32x4 p = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.wpe) + (size_t)s * a.n_embed + e);
             o = t + p;
         }
-        if (a.xg) {  // (one sequence) x as granules for the kernels of the other stream: tag = new step << 8 | writer 1
-            const unsigned long long tg = (unsigned long long)(((*a.epoch2 + 1u) << 8) | 1u) << 32;
-            unsigned long long* xgp = a.xg + e;
-            __hip_atomic_store(xgp + 0, tg | __float_as_uint(o.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(xgp + 1, tg | __float_as_uint(o.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(xgp + 2, tg | __float_as_uint(o.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(xgp + 3, tg | __float_as_uint(o.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else
-            *reinterpret_cast<f32x4*>(a.x + (size_t)b * a.n_embed + e) = o;
+        *reinterpret_cast<f32x4*>(a.x + (size_t)b * a.n_embed + e) = o;
         if (a.pl_out) {  // the first Linear of the lock-step batch reads its input as planes of g * x
             const f32x4 v = o * *reinterpret_cast<const f32x4*>(a.pl_g + e);
             uint32_t h0, m0, l0, h1, m1, l1;
@@ -278,10 +270,6 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         }
     }
     if (threadIdx.x == 0 && a.epoch) *a.epoch += 1u;  // a step starts: new tags for its hand-overs
-    if (a.xg) {  // ... and of the two-stream decode (every thread has read the old value above: barrier, then one store)
-        __syncthreads();
-        if (threadIdx.x == 0) *a.epoch2 += 1u;
-    }
     if (threadIdx.x == 0 && a.finish_only == 0) {
         a.ctrl->seq_len = s + 1;
         a.ctrl->step = s + 1;

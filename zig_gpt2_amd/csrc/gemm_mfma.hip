@@ -525,10 +525,7 @@ int launch_p8_bn(const bf16_t* A, const bf16_t* B, const float* bias, void* C, i
 static unsigned long long g_gemm_launches = 0;
 unsigned long long gemm_mfma_launch_count() { return g_gemm_launches; }
 void gemm_note_launch() { ++g_gemm_launches; }
-static int g_last_gemm_kernel = 0;  // 0 s4 / p8, 1 ov
-int gemm_debug_stamps(unsigned long long* out, size_t n_words) {
-    return g_last_gemm_kernel == 1 ? gemm_ov_stamps(out, n_words) : gemm_s4_stamps(out, n_words);
-}
+int gemm_debug_stamps(unsigned long long* out, size_t n_words) { return gemm_s4_stamps(out, n_words); }
 
 int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl,
                        int ldc, bool gelu, bool out_bf16, hipStream_t s) {
@@ -569,16 +566,10 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     ++g_gemm_launches;
     // Two generations of the kernel: the four-wave software-pipelined one (gemm_s4.hip) wherever 192-wide tiles are the
     // choice (its 256-wide instantiation does not fit the register file without spills yet), the eight-wave one below
-    // for 256-wide tiles.  ZGPT2_GEMM_KERNEL=p8 / s4 forces one (s4 then always with 192-wide tiles).
+    // for 256-wide tiles.  ZGPT2_GEMM_KERNEL=p8 / s4 forces one (s4 then always with 192-wide tiles).  (The third generation —
+    // a tile's epilogue under the next tile's main loop, bitwise equal and slower — lives in tools/experiments/gemm_ov.hip.)
     const char* kk = getenv("ZGPT2_GEMM_KERNEL");
-    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8"), force_ov = kk && !strcmp(kk, "ov");
-    // bf16 results: the third generation (gemm_ov.hip) hides a tile's epilogue under the next tile's main loop
-    // — measured SLOWER than gemm_s4 at two tiles per workgroup: an experiment, only on request
-    if (out_bf16 && gemm_ov_args_ok(M, pl, ldc) && force_ov) {
-        g_last_gemm_kernel = 1;
-        return launch_gemm_ov(A, B, bias, C, M, N, pl, ldc, gelu, s);
-    }
-    g_last_gemm_kernel = 0;
+    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8");
     // The four-wave kernel packs its arguments (gemm_s4_args_ok: lda / ldb < 65536, K < 16384 per plane, <= 6 plane pairs);
     // a shape beyond that runs on the eight-wave kernel — unless it is ragged, which only the four-wave kernel stores.
     const bool s4_ok = gemm_s4_args_ok(pl, ldc);

@@ -191,7 +191,7 @@ __device__ __forceinline__ void read_b_all(bf16x8 (&fb)[4][NT], const unsigned (
 //   S4_SPLIT3   bias + GELU, then the exact three-term bf16 split as planes C[M][3N] = [hi | mid | lo]  (src/main.zig:79-80 feeding
 //               the next Linear's A operand)
 
-template <int NT, int KIND, bool GELU, bool OUT_BF16, int ABL>
+template <int NT, int KIND, bool GELU, bool OUT_BF16>
 __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, void* __restrict__ C, int M, int N,
                                                          unsigned p0, unsigned p1, unsigned p2, unsigned p3, const PrefillQkv qa) {
@@ -319,22 +319,16 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         return s;
     };
     // piece i (0..3) of A half h of stream position s -> slot X
-    // diagnostic ablations, compile time (ZGPT2_S4_ABL; timing only, wrong results): 1 no DMA, 2 no barriers, 4 no fragment reads,
-    // 8 no waits on the fragment reads
-    constexpr bool abl_dma = ABL & 1, abl_bar = ABL & 2, abl_rd = ABL & 4, abl_lgkm = ABL & 8;
     // Cache policy of the bf16 output stores: sc1 = write-through.  With plain stores the launch ends with the L2s writing
     // their dirty lines back — 4.2 us between the last workgroup's end and the next launch's first workgroup against 2.0 us
-    // with write-through stores, at +0.6 us inside the launch (41.5 -> 40.2 us at M = 8192, profiles/round4_gemm_a.txt).
-    // A/B: ABL bits 16 / 32 -> nt (aux 2), plain (0), sc0 sc1 (17).
-    constexpr int ST_AUX = ((ABL >> 4) & 3) == 1 ? 2 : ((ABL >> 4) & 3) == 2 ? 0 : ((ABL >> 4) & 3) == 3 ? 17 : 16;
+    // with write-through stores, at +0.6 us inside the launch (41.5 -> 40.2 us at M = 8192, profiles/round4_gemm_a.txt; nt: 40.7).
+    constexpr int ST_AUX = 16;
     auto dma_a = [&](int X, int h, int i, const Ahead& s) {
-        if constexpr (abl_dma) return;
         const unsigned rowd = (unsigned)((i >> 1) * 128 + h * 64 + (i & 1) * 32);
         const unsigned dst = lds_base + P::A_OFF + X * P::A_SLOT + h * 16384 + (wave + 4 * i) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, to_lds(dst), 16, relA, s.baseA + rowd * lda2 + s.kbA, 0, 0);
     };
     auto dma_b = [&](int X, int i, const Ahead& s) {
-        if constexpr (abl_dma) return;
         const unsigned dst = lds_base + P::B_OFF + X * P::B_SLOT + (wave + 4 * i) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, to_lds(dst), 16, relB, s.baseB + (unsigned)(i * 32) * ldb2 + s.kbB, 0, 0);
     };
@@ -363,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
 
     auto bar = [&]() {
         ZG_SB();
-        if constexpr (!abl_bar) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         ZG_SB();
     };
     // all B fragments + the A fragments of step 0 of the K-step in slot X (kernel start: nothing else is in flight)
@@ -476,11 +470,11 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             ZG_SB();
             if constexpr (m == 0) {
                 if constexpr (J == 0) s2 = ahead(2);
-                if constexpr (!abl_rd) read_frag_a<NT, XN, JN, 0>(fa[nb][0], a_addr);
+                read_frag_a<NT, XN, JN, 0>(fa[nb][0], a_addr);
             } else if constexpr (m == a1_gap) {
-                if constexpr (!abl_rd) read_frag_a<NT, XN, JN, 1>(fa[nb][1], a_addr);
+                read_frag_a<NT, XN, JN, 1>(fa[nb][1], a_addr);
             } else if constexpr (b_reads && m >= b_gap0 && m < b_gap0 + NT) {
-                if constexpr (!abl_rd) read_frag_b<NT, X ^ 1, J - 3, m - b_gap0>(fb[X ^ 1][J - 3][m - b_gap0], b_addr);
+                read_frag_b<NT, X ^ 1, J - 3, m - b_gap0>(fb[X ^ 1][J - 3][m - b_gap0], b_addr);
             } else if constexpr (m >= d_gap0 && m - d_gap0 < nd) {
                 constexpr int d = m - d_gap0;
                 if constexpr (J <= 2) {
@@ -495,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         auto mma = [&](auto MT) {
             constexpr int m = decltype(MT)::value, i = m / NT, j = m % NT;
             // A operands: tile 0 was the FIRST read of the step before, tile 1 its LAST (steps 3 and 7 start behind lgkmcnt(0))
-            if constexpr (!abl_lgkm && J != 3 && J != 7) {
+            if constexpr (J != 3 && J != 7) {
                 if constexpr (m == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(lenp - 1) : "memory");
                 if constexpr (m == NT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(mine) : "memory");
                 if constexpr (m == 0 || m == NT) ZG_SB();
@@ -860,13 +854,13 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     }
 }
 
-template <int NT, int KIND, bool GELU, bool OUT_BF16, int ABL>
-int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, int n_sl,
+template <int NT, int KIND, bool GELU, bool OUT_BF16>
+int launch_s4_kind(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, int n_sl,
                   const PrefillQkv& qa, hipStream_t s) {
     using P = S4<NT>;
     static bool raised = false;
     if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, ABL>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, KIND, GELU, OUT_BF16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
         raised = true;
     }
@@ -885,7 +879,7 @@ int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, 
         pa2 |= ((pl.pa_bits >> (4 * i)) & 3u) << (2 * i);
         pb2 |= ((pl.pb_bits >> (4 * i)) & 3u) << (2 * i);
     }
-    hipLaunchKernelGGL((gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, ABL>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
+    hipLaunchKernelGGL((gemm_s4_kernel<NT, KIND, GELU, OUT_BF16>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
                        (unsigned)pl.lda | ((unsigned)pl.ldb << 16), (unsigned)ldc | ((unsigned)pl.kpp << 20) | ((unsigned)pl.npairs << 28),
                        pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10) | ((unsigned)n_sl << 20), qa);
     ZG_HIP(hipGetLastError());
@@ -895,24 +889,7 @@ int launch_s4_abl(const bf16_t* A, const bf16_t* B, const float* bias, void* C, 
 template <int NT, bool GELU, bool OUT_BF16>
 int launch_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, hipStream_t s) {
     const PrefillQkv none{};
-    if constexpr (NT == 3 && GELU && OUT_BF16) {  // the benchmarked instantiation carries the ablation builds
-        const int abl = getenv("ZGPT2_S4_ABL") ? atoi(getenv("ZGPT2_S4_ABL")) : 0;
-        switch (abl) {
-            case 1: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 1>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 2: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 2>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 3: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 3>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 4: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 4>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 7: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 7>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 8: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 8>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 9: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 9>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 11: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 11>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 16: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 16>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 32: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 32>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            case 48: return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 48>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
-            default: break;
-        }
-    }
-    return launch_s4_abl<NT, S4_PLAIN, GELU, OUT_BF16, 0>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
+    return launch_s4_kind<NT, S4_PLAIN, GELU, OUT_BF16>(A, B, bias, C, M, N, pl, ldc, 1, none, s);
 }
 
 template <int NT>
@@ -969,13 +946,13 @@ int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, 
     switch (kind) {
         case S4_PARTIAL:
             ZG_REQUIRE(bias == nullptr, ZG_ERR_ARG, "s4 prefill gemm: partial slabs carry no bias");
-            return launch_s4_abl<3, S4_PARTIAL, false, false, 0>(A, W, nullptr, C, M, N, pl, ldc, n_slices, none, s);
+            return launch_s4_kind<3, S4_PARTIAL, false, false>(A, W, nullptr, C, M, N, pl, ldc, n_slices, none, s);
         case S4_QKV:
             ZG_REQUIRE(qkv && N == 3 * qkv->E && n_slices == 1, ZG_ERR_ARG, "s4 prefill gemm: S4_QKV needs the cache description");
-            return launch_s4_abl<3, S4_QKV, false, false, 0>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
+            return launch_s4_kind<3, S4_QKV, false, false>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
         case S4_SPLIT3:
             ZG_REQUIRE(n_slices == 1, ZG_ERR_ARG, "s4 prefill gemm: S4_SPLIT3 is not sliced");
-            return launch_s4_abl<3, S4_SPLIT3, true, true, 0>(A, W, bias, C, M, N, pl, ldc, 1, none, s);
+            return launch_s4_kind<3, S4_SPLIT3, true, true>(A, W, bias, C, M, N, pl, ldc, 1, none, s);
     }
     ZG_REQUIRE(false, ZG_ERR_ARG, "s4 prefill gemm: kind %d", kind);
 }

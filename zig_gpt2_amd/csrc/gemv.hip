@@ -149,15 +149,7 @@ bool gemv_pl4_ok(const GemvArgs& a, int weight_type) {
 
 bool gemv_planes_producer_ok(const GemvArgs& a, int weight_type) { return a.epilogue != EPI_ARGMAX && gemv_use_mfma(a, weight_type); }
 
-// Whether this M == 1 launch runs on one of the two kernels that know x as granules (GemvArgs.xg): the K-split kernel
-// (residual / output) or the linearised-LayerNorm kernel (input).
-bool gemv_xg_ok(const GemvArgs& a, int weight_type) {
-    if (a.M != 1 || gemv_use_mfma(a, weight_type)) return false;
-    return gemv_use_ksplit(a) || gemv_use_lnk(a);
-}
-
 int launch_gemv(const GemvArgs& a, int weight_type, int grid, hipStream_t s) {
-    ZG_REQUIRE(a.xg == nullptr || gemv_xg_ok(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: granule input / output asked of a launch outside the K-split kernels");
     ZG_REQUIRE(a.pl_in == nullptr || gemv_planes_ok(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: input planes given to a launch outside the matrix-core path");
     ZG_REQUIRE(a.pl_out == nullptr || gemv_use_mfma(a, weight_type), ZG_ERR_UNSUPPORTED, "gemv: output planes asked of a launch outside the matrix-core path");
     if (gemv_use_mfma(a, weight_type)) return launch_gemv_mfma(a, grid, s);

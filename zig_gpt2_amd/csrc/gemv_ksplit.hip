@@ -19,12 +19,10 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
                                                           int K, unsigned em, const float* __restrict__ part_in, int max_splits,
                                                           const float* __restrict__ bias, const float* __restrict__ resid,
                                                           const GemvArgs a) {
-    // 14 preloaded dwords: Wv, xin, N, K, em = epilogue | merge_splits << 8 | has_bias << 16 | has_resid << 17 | xg_resid << 18
-    // | xg_out << 19, the attention partials and their split stride, bias and residual (a few zero floats when absent:
-    // read at index 0)
+    // 14 preloaded dwords: Wv, xin, N, K, em = epilogue | merge_splits << 8 | has_bias << 16 | has_resid << 17, the attention
+    // partials and their split stride, bias and residual (a few zero floats when absent: read at index 0)
     const int epilogue = (int)(em & 0xffu), merge_splits = (int)((em >> 8) & 0xffu);
     const int has_bias = (int)((em >> 16) & 1u), has_resid = (int)((em >> 17) & 1u);
-    const int xg_res = (int)((em >> 18) & 1u), xg_out = (int)((em >> 19) & 1u);  // two-stream decode: GemvArgs.xg
     ZG_STAMP_DECL();
     ZG_STAMP(0);
     // merge_splits > 0 (attn c_proj): the input is the head merge of the attention partials — every lane combines
@@ -90,19 +88,15 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
         for (int i = 0; i < CPL; ++i) xr[i] = load_x8(xin + (size_t)wave * Kq + (size_t)min(lr + LPR * i, nchq - 1) * 8);
     }
     float bias_n = 0.0f, resid_n = 0.0f;
-    unsigned long long resid_g = 0;
-    // (the granule buffer, or the zero words as its stand-in: both loads are unconditional — a load inside a uniform branch
+    // (absent operands are a few zero words read at index 0: the loads are unconditional — a load inside a uniform branch
     // whose result is merged with a constant makes the compiler wait at the join for every load issued before it)
-    const unsigned long long* xgp = xg_res ? a.xg : reinterpret_cast<const unsigned long long*>(a.zero);
     if (tid < ROWS) {
         const int n = min(row0 + tid, N - 1);
         bias_n = bias[n * has_bias];
-        resid_n = resid[n * (has_resid & (xg_res ^ 1))];
-        resid_g = __hip_atomic_load(xgp + n * xg_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        resid_n = resid[n * has_resid];
     }
     ZG_STAMP(1);
     ZG_PIN(a.y);  // the tail's argument-block fields, fetched under the vector loads (zg_common.h ZG_PIN)
-    ZG_PIN(a.xg); ZG_PIN(a.epoch2); ZG_PIN(a.xout_id);
     ZG_PIN(a.progress);
     pf_count(a.progress);
     ZG_STAMP(2);
@@ -134,13 +128,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const void* __restrict
     if (tid < ROWS && row0 + tid < N) {
         const int n = row0 + tid;
         const float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + bias_n;
-        if (xg_res) resid_n = __uint_as_float((unsigned)resid_g);
-        const float out = epilogue == EPI_RESIDUAL ? v + resid_n : (epilogue == EPI_GELU ? gelu_ref(v) : v);
-        if (xg_out) {  // (value, tag) in one 8-byte agent-scope store: the consumer on the other stream polls the tag
-            const unsigned long long tg = (unsigned long long)((*a.epoch2 << 8) | a.xout_id) << 32;
-            __hip_atomic_store(a.xg + n, tg | __float_as_uint(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else
-            a.y[n] = out;
+        a.y[n] = epilogue == EPI_RESIDUAL ? v + resid_n : (epilogue == EPI_GELU ? gelu_ref(v) : v);
     }
     ZG_STAMP(5);
     ZG_STAMP(6);
@@ -153,9 +141,7 @@ int launch_ksplit(const GemvArgs& a, hipStream_t s) {
     const int nchq = a.K / 32;  // 16-B chunks per quarter row
     const int merge_splits = a.prologue == PRO_ATTN_MERGE ? (a.t_hi + kAttnChunk - 1) / kAttnChunk : 0;
     const unsigned has_resid = a.epilogue == EPI_RESIDUAL ? 1u : 0u;
-    const unsigned xg_res = (a.xg && a.xg_resid && has_resid) ? 1u : 0u, xg_out = (a.xg && a.xout_id) ? 1u : 0u;
-    const unsigned em = (unsigned)a.epilogue | ((unsigned)merge_splits << 8) | ((a.bias ? 1u : 0u) << 16) | (has_resid << 17) | (xg_res << 18) |
-                        (xg_out << 19);
+    const unsigned em = (unsigned)a.epilogue | ((unsigned)merge_splits << 8) | ((a.bias ? 1u : 0u) << 16) | (has_resid << 17);
     // two passes of 64 / LPR rows per workgroup (four measured slower: 2.65 -> 3.3 us for mlp c_proj)
 #define ZG_KS(LPR_, CPL_)                                                                                                \
     {                                                                                                                    \
@@ -164,7 +150,7 @@ int launch_ksplit(const GemvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemv_ksplit_kernel<WT, LPR_, CPL_, 2>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W,     \
                            a.x,                                                                                         \
                            a.N, a.K, em, a.part ? a.part : a.zero, a.max_splits, a.bias ? a.bias : a.zero,              \
-                           (has_resid && !xg_res) ? a.resid : a.zero, a);                                                \
+                           has_resid ? a.resid : a.zero, a);                                                             \
         ZG_HIP(hipGetLastError());                                                                                       \
         return ZG_OK;                                                                                                    \
     }
@@ -192,7 +178,7 @@ int launch_ksplit(const GemvArgs& a, hipStream_t s) {
 // third of its time in the dependent chain load x -> two wave reductions -> normalise -> LDS -> registers before
 // its first FMA.  (Same real-number result; in floating point r (S1 - mu c2) cancels when |mu| >> sigma, which costs
 // log2(|mu| / sigma) bits of the fp32 product sums — far inside the 1e-3 bound for any LayerNorm input.)
-template <typename WT, int LPR, int CPL, int NP = 2, bool XG = false>  // NP passes of 64 / LPR rows per workgroup; XG: x as granules
+template <typename WT, int LPR, int CPL, int NP = 2>  // NP passes of 64 / LPR rows per workgroup
 __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ Wv, const float* __restrict__ xin, unsigned ne, int K,
                                                        const float* __restrict__ ln_g, const float* __restrict__ c2,
                                                        const float* __restrict__ c3, const int* __restrict__ cw,
@@ -233,7 +219,7 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const size_t off = (size_t)kbeg + (size_t)min(lr + LPR * i, nchq - 1) * 8;
-        if constexpr (!XG) xr[i] = load_x8(xin + off);
+        xr[i] = load_x8(xin + off);
         gr[i] = load_x8(ln_g + off);
     }
     float c2n = 0.0f, c3n = 0.0f;
@@ -243,59 +229,9 @@ __global__ __launch_bounds__(256) void gemv_lnk_kernel(const void* __restrict__ 
         c3n = c3[n];
     }
     const int T = max(cw[1], 1);  // KV append position (EPI_QKV)
-    if constexpr (XG) {
-        // Two-stream decode: x arrives as (value, tag) granules from a kernel of the OTHER stream, possibly still running — this
-        // kernel was launched beside it and has its weights and LayerNorm vectors in flight.  xin = the granules; every lane
-        // polls the chunks it multiplies (16-byte agent-scope loads of two granules, each granule one 8-byte store of its
-        // writer) until all carry (epoch2 << 8 | xin_id); xin_id == 0: the input is known to be complete, one pass.
-        const unsigned want = (*a.epoch2 << 8) | a.xin_id;
-        const bool poll = a.xin_id != 0;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (unsigned)K * 8u, 0x00020000);
-        // Cheap wait first: the whole wave watches ONE granule of its K quarter (a single request per poll) until it carries the
-        // tag — with every lane of 1024 waves re-reading its 16 granules the pollers alone moved ~8 MB per round through the
-        // L2s and slowed the producers they were waiting for (269 against 212 us per token).  The writers of x finish within
-        // a fraction of a microsecond of each other, so the full check below then passes on its first or second round.
-        unsigned spins = 0;
-        if (poll) {
-            const unsigned long long* g0 = reinterpret_cast<const unsigned long long*>(xin) + kbeg;
-            while ((unsigned)(__hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != want && spins < a.spin_limit) {
-                if (a.xout_id >= 4) __builtin_amdgcn_s_sleep(8);       // (xout_id is unused by this kernel: carries the A/B knob
-                else if (a.xout_id >= 2) __builtin_amdgcn_s_sleep(4);  //  ZGPT2_DUAL_SLEEP of the poll pause)
-                else if (a.xout_id >= 1) __builtin_amdgcn_s_sleep(2);
-                else __builtin_amdgcn_s_sleep(1);
-                ++spins;
-            }
-        }
-        for (;; ++spins) {
-            asm volatile("" ::: "memory");  // (the loads below are plain intrinsics: without this the compiler hoists them out of the loop)
-            u32x4 gq[CPL][4];
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                const unsigned off = ((unsigned)kbeg + (unsigned)min(lr + LPR * i, nchq - 1) * 8u) * 8u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gq[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + 16u * j, 0, 16);  // sc1
-            }
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < CPL; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ok = ok && gq[i][j].y == want && gq[i][j].w == want;
-                    xr[i].v[2 * j] = __uint_as_float(gq[i][j].x);
-                    xr[i].v[2 * j + 1] = __uint_as_float(gq[i][j].z);
-                }
-            if (!poll || __builtin_amdgcn_ballot_w64(!ok) == 0) break;
-            if (spins >= a.spin_limit) {  // bounded: never hang the queue — and never pass silently
-                if (lane == 0 && a.fault) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
     ZG_STAMP(1);
     {   // the argument-block fields of the tail, fetched under the vector loads (zg_common.h ZG_PIN)
         ZG_PIN(a.progress); ZG_PIN(a.y); ZG_PIN(a.y_stride); ZG_PIN(a.epilogue); ZG_PIN(__float_as_uint(a.eps));
-        if constexpr (XG) { ZG_PIN(a.fault); ZG_PIN(a.spin_limit); }
         if (epilogue == EPI_QKV) {
             ZG_PIN(a.q); ZG_PIN(a.k_cache); ZG_PIN(a.v_cache); ZG_PIN(a.N); ZG_PIN(a.head_dim); ZG_PIN(a.n_heads); ZG_PIN(a.ctx); ZG_PIN(a.kv_mode); ZG_PIN(a.kv_lo);
         }
@@ -390,15 +326,10 @@ int launch_lnk(const GemvArgs& a, hipStream_t s) {
 #define ZG_LK(LPR_, CPL_)                                                                                              \
     {                                                                                                                  \
         constexpr int rows = 4 * (64 / LPR_);                                                                          \
-        note_kernel("gemv_lnk_kernel<%s, %d, %d, 4%s>", sizeof(WT) == 2 ? "unsigned short" : "float", LPR_, CPL_, a.xg ? ", granules" : ""); \
-        if (a.xg)                                                                                                      \
-            hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_, 4, true>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, \
-                               reinterpret_cast<const float*>(a.xg), (unsigned)a.N | ((unsigned)a.epilogue << 24), a.K, a.ln_g,  \
-                               a.ln_c2, a.ln_c3, a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_, 4>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
-                               (unsigned)a.N | ((unsigned)a.epilogue << 24), a.K, a.ln_g, a.ln_c2, a.ln_c3,             \
-                               a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a); \
+        note_kernel("gemv_lnk_kernel<%s, %d, %d, 4>", sizeof(WT) == 2 ? "unsigned short" : "float", LPR_, CPL_);       \
+        hipLaunchKernelGGL((gemv_lnk_kernel<WT, LPR_, CPL_, 4>), dim3((a.N + rows - 1) / rows), dim3(256), 0, s, a.W, a.x, \
+                           (unsigned)a.N | ((unsigned)a.epilogue << 24), a.K, a.ln_g, a.ln_c2, a.ln_c3,                 \
+                           a.ctrl ? reinterpret_cast<const int*>(a.ctrl) : reinterpret_cast<const int*>(a.zero), a);   \
         ZG_HIP(hipGetLastError());                                                                                     \
         return ZG_OK;                                                                                                  \
     }

@@ -7,8 +7,8 @@
 // into three bf16 terms, x = hi + mid + lo EXACTLY (24 = 8 + 8 + 8 mantissa bits; a two-term split leaves
 // 2^-18 |x| behind, which showed up as 2e-5 of the logit scale — outside the parity bar for logits that
 // happen to lie near zero), laid out [M][3K] = [hi | mid | lo]; every staged weight tile is multiplied with
-// the three planes, so C = (hi + mid + lo) W^T accumulates in one fp32 MFMA chain.  Attention runs on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): no rounding of q, k,
-// v or the probabilities at all.
+// the three planes, so C = (hi + mid + lo) W^T accumulates in one fp32 MFMA chain.  Attention (attn_prefill.hip) splits q, k, v
+// and the probabilities the same way and multiplies the six plane products above 2^-24.
 //
 // Kernels
 //   embed_prefill      x[m] = wte[token[m]] + wpe[t]                         (src/main.zig:179-183)
@@ -17,8 +17,7 @@
 //                      buffer, epilogues:
 //                        F32 store | fp32 residual add | GELU + split        (ops.zig:21-46, main.zig:136-145, :79-80)
 //   (cache append)     K / V columns of the qkv rows -> head-major caches, in the c_attn GEMM epilogue (ops.zig:152-158)
-//   attn_prefill       causal softmax(q k^T / 8) v, flash style, transposed so that every per-query
-//                      statistic lives in one lane                           (src/ops.zig:249-307)
+//   (attention)        causal softmax(q k^T / 8) v for all positions: attn_prefill.hip           (src/ops.zig:249-307)
 #include <stdlib.h>
 
 #include "prefill_epi.h"
@@ -618,191 +617,6 @@ int launch_prefill_gemm_t(const bf16_t* A, const bf16_t* B, const float* bias, v
     return launch_prefill_gemm_ns<EPI, 1>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, ln, qa, nsplit, s);
 }
 
-// ------------------------------------------------------------------------------------------ attention
-// Grid (ceil(nqb / 2), H, B), 4 waves, nqb = ceil(P / 32) query blocks.  A workgroup processes query
-// block x and then its mirror nqb - 1 - x, so causal work (x + 1 and nqb - x key tiles) is the same for
-// every workgroup wherever the dispatcher places it.  Within a block wave w takes the 32-key tiles w,
-// w + 4, ... up to the diagonal (split-KV, merged at the end): ~8 tiles per wave for a 1024-token prompt.  Tiles are wave-private (own LDS strip, no workgroup barrier in
-// the loop); the next tile's global loads are in flight while the current one is multiplied.  Per tile:
-//     S^T = K Q^T   32 x v_mfma_f32_32x32x2_f32   (A = K tile rows, B = the lane's own query, pre-scaled by 1/8)
-//     online softmax: the lane's 16 accumulator registers + its partner lane ^ 32 are one query's 32 scores
-//     O^T += V^T P^T  2 x 16 MFMAs               (B = the lane's probabilities, no transpose needed)
-// The k index of an MFMA step only has to agree between A and B, so step i of the second product pairs
-// the keys {(i & 3) + 8 (i >> 2) + 4 half}, exactly the rows the lane already holds.  Everything is
-// transposed (keys / head dims along the accumulator rows, the query along lanes) so that each per-query
-// statistic is one register of one lane.
-constexpr int kKS = 68, kVS = 72;  // padded LDS row strides (floats): conflict-free fragment reads
-constexpr int kAttnWaveLds = (32 * kKS + 32 * kVS) * 4;  // 17920 B per wave
-constexpr int kAttnLds = 4 * kAttnWaveLds;
-
-struct KvRegs {
-    f32x4 k[8], v[8];
-};
-
-__device__ __forceinline__ void kv_load(KvRegs& r, const float* __restrict__ qkv, size_t row0, int P, int ld, int E, int h,
-                                        int kt, int lane) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int idx = lane + 64 * j, row = idx >> 4, c4 = (idx & 15) * 4;
-        const float* src = qkv + (row0 + min(kt * 32 + row, P - 1)) * ld + h * 64 + c4;
-        r.k[j] = *reinterpret_cast<const f32x4*>(src + E);
-        r.v[j] = *reinterpret_cast<const f32x4*>(src + 2 * E);
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ out, int P,
-                                                              int E) {
-    extern __shared__ __attribute__((aligned(16))) char attn_lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l32 = lane & 31, hl = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const size_t row0 = (size_t)b * P;
-    const int ld = 3 * E;
-    float* sK = reinterpret_cast<float*>(attn_lds + wave * kAttnWaveLds);
-    float* sV = sK + 32 * kKS;
-    const int nqb = (P + 31) >> 5;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int qb = pass ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    if (pass && qb == (int)blockIdx.x) break;  // odd block count: the middle block is its own mirror
-    const int tq = qb * 32 + l32;
-
-    float qreg[32];
-    {
-        const float* qp = qkv + (row0 + min(tq, P - 1)) * ld + h * 64 + hl * 32;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + c * 4);
-            qreg[c * 4 + 0] = v.x * 0.125f;  // 1 / sqrt(head_dim): exact scaling (ops.zig:275 applies it as sgemm alpha)
-            qreg[c * 4 + 1] = v.y * 0.125f;
-            qreg[c * 4 + 2] = v.z * 0.125f;
-            qreg[c * 4 + 3] = v.w * 0.125f;
-        }
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.0f;
-    float mrun = -INFINITY, lrun = 0.0f;
-
-    KvRegs nxt;
-    if (wave <= qb) kv_load(nxt, qkv, row0, P, ld, E, h, wave, lane);
-    for (int kt = wave; kt <= qb; kt += 4) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = lane + 64 * j, row = idx >> 4, c4 = (idx & 15) * 4;
-            *reinterpret_cast<f32x4*>(&sK[row * kKS + c4]) = nxt.k[j];
-            *reinterpret_cast<f32x4*>(&sV[row * kVS + c4]) = nxt.v[j];
-        }
-        if (kt + 4 <= qb) kv_load(nxt, qkv, row0, P, ld, E, h, kt + 4, lane);
-        __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: no s_barrier needed
-
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(&sK[l32 * kKS + hl * 32 + c * 4]);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[c * 4 + 0], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[c * 4 + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[c * 4 + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[c * 4 + 3], s, 0, 0, 0);
-        }
-        // s[r] = score of key kt*32 + (r & 3) + 8 (r >> 2) + 4 hl against query tq
-        float mx = -INFINITY;
-        if (kt == qb) {  // diagonal tile: causal mask (decode at position tq sees keys 0..tq); also hides rows >= P
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                s[r] = key <= tq ? s[r] : -INFINITY;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx);  // finite: every tile has at least one visible key per query
-        const float corr = __expf(mrun - mnew);
-        float psum = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - mnew);
-            psum += s[r];
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        lrun = lrun * corr + psum;
-        mrun = mnew;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= corr;
-            o1[r] *= corr;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = (i & 3) + 8 * (i >> 2) + 4 * hl;
-            const float v0 = sV[key * kVS + l32], v1 = sV[key * kVS + 32 + l32];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[i], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[i], o1, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // merge the four key slices: waves 1..3 publish (m, l, O^T) in their own strip, wave 0 combines
-    float* strip = reinterpret_cast<float*>(attn_lds + wave * kAttnWaveLds);
-    if (wave > 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<f32x4*>(&strip[(g * 64 + lane) * 4]) = f32x4{o0[g * 4], o0[g * 4 + 1], o0[g * 4 + 2], o0[g * 4 + 3]};
-            *reinterpret_cast<f32x4*>(&strip[1024 + (g * 64 + lane) * 4]) = f32x4{o1[g * 4], o1[g * 4 + 1], o1[g * 4 + 2], o1[g * 4 + 3]};
-        }
-        strip[2048 + lane] = mrun;
-        strip[2112 + lane] = lrun;
-    }
-    __syncthreads();
-    if (wave == 0 && tq < P) {
-    float mw[3], mall = mrun;
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        mw[w - 1] = reinterpret_cast<const float*>(attn_lds + w * kAttnWaveLds)[2048 + lane];
-        mall = fmaxf(mall, mw[w - 1]);
-    }
-    {
-        const float c0 = __expf(mrun - mall);
-        lrun *= c0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= c0;
-            o1[r] *= c0;
-        }
-    }
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const float* st = reinterpret_cast<const float*>(attn_lds + w * kAttnWaveLds);
-        const float cw = __expf(mw[w - 1] - mall);  // 0 for a slice that saw no tile (m = -inf, l = 0)
-        lrun += st[2112 + lane] * cw;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&st[(g * 64 + lane) * 4]);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(&st[1024 + (g * 64 + lane) * 4]);
-            o0[g * 4 + 0] += a.x * cw; o0[g * 4 + 1] += a.y * cw; o0[g * 4 + 2] += a.z * cw; o0[g * 4 + 3] += a.w * cw;
-            o1[g * 4 + 0] += c.x * cw; o1[g * 4 + 1] += c.y * cw; o1[g * 4 + 2] += c.z * cw; o1[g * 4 + 3] += c.w * cw;
-        }
-    }
-    // O^T: lane holds d = (r & 3) + 8 (r >> 2) + 4 hl (+ 32 for o1) of its query; softmax divides by the sum (ops.zig:239)
-    const float inv = 1.0f / lrun;
-    bf16_t* hi = out + (row0 + tq) * kSplit * E + h * 64;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int d = 8 * g + 4 * hl;
-        f32x4 a, c;
-        a.x = o0[g * 4 + 0] * inv; a.y = o0[g * 4 + 1] * inv; a.z = o0[g * 4 + 2] * inv; a.w = o0[g * 4 + 3] * inv;
-        c.x = o1[g * 4 + 0] * inv; c.y = o1[g * 4 + 1] * inv; c.z = o1[g * 4 + 2] * inv; c.w = o1[g * 4 + 3] * inv;
-        store_split4(hi + d, E, a);
-        store_split4(hi + 32 + d, E, c);
-    }
-    }
-    __syncthreads();  // strips are free again for the mirror block's tiles
-  }
-}
-
 }  // namespace
 
 int launch_embed_prefill(const int* tokens, int token_stride, int B, int P, const void* wte, const void* wpe,
@@ -882,19 +696,6 @@ int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, voi
             return launch_prefill_gemm_t<PF_QKV>(A, B, bias, C, M, N, K, ldc, ws, ws_floats, nullptr, *qkv, nsplit, s);
     }
     ZG_REQUIRE(false, ZG_ERR_ARG, "prefill gemm: epilogue %d", epi);
-}
-
-int launch_attn_prefill_f32(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s) {
-    static bool raised = false;
-    if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds));
-        raised = true;
-    }
-    const int nqb = (P + 31) / 32;
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3((nqb + 1) / 2, H, B), dim3(256), kAttnLds, s, qkv, out, P, E);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
 }
 
 #ifdef ZG_PF_STAMPS

@@ -91,15 +91,6 @@ struct GemvArgs {
     float* st_out;
     const float* st_in;
     const float* zero;        // device pointer to a few zero floats (stand-in for absent bias / residual)
-    // Two-stream decode of one sequence (api_gpt.hip "dual"): the residual stream x lives as (value, tag) granules xg[E], so
-    // that a kernel of the OTHER stream — already resident, its weights in registers — can take it over the moment it is
-    // written instead of behind a kernel boundary.  tag = *epoch2 << 8 | id; epoch2 is the step counter of the graph the
-    // launch belongs to (both graphs count the same steps), ids name the writers of x within a step.
-    unsigned long long* xg;   // LayerNorm-fed M == 1 kernels: the input; EPI_RESIDUAL M == 1 kernels: residual and / or output
-    const unsigned* epoch2;
-    unsigned xin_id;          // != 0: poll until every input granule carries this id (0: the input is known to be complete)
-    unsigned xout_id;         // != 0: the output row goes to xg with this id instead of y
-    unsigned xg_resid;        // the residual is read from xg (value half, agent scope) instead of resid
     unsigned long long* dbg;  // diagnostic timestamps (only read by -DZG_STAMPS builds)
     unsigned* progress;       // launch counter followed by the side-stream prefetcher (prefetch.hip); null = not counted
 };
@@ -112,8 +103,6 @@ bool gemv_planes_ok(const GemvArgs& a, int weight_type);
 bool gemv_planes_producer_ok(const GemvArgs& a, int weight_type);
 // Whether a planned plane-fed launch runs as the four-wave kernel (the one that writes / reads the tile statistics).
 bool gemv_pl4_ok(const GemvArgs& a, int weight_type);
-// Whether an M == 1 launch honours GemvArgs.xg (x as granules: the two-stream decode).
-bool gemv_xg_ok(const GemvArgs& a, int weight_type);
 // Fills rows_per_wave and returns the grid size for the given problem.
 int gemv_plan(GemvArgs& a, int weight_type = WT_F32);
 int gemv_kslices(const GemvArgs& a);
@@ -195,11 +184,6 @@ struct PrefillQkv;
 int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int nplanes, int kind, int n_slices,
                            const PrefillQkv* qkv, hipStream_t s);
 int gemm_s4_stamps(unsigned long long* out, size_t n_words);  // diagnostic (ZGPT2_GEMM_DBG bit 256)
-// bf16 result, 192-wide tiles, the epilogue of a tile under the next tile's main loop (gemm_ov.hip)
-bool gemm_ov_args_ok(int M, const GemmPlanes& pl, int ldc);
-int launch_gemm_ov(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, bool gelu,
-                   hipStream_t s);
-int gemm_ov_stamps(unsigned long long* out, size_t n_words);
 int gemm_debug_stamps(unsigned long long* out, size_t n_words);  // of the kernel generation launched last
 unsigned long long gemm_mfma_launch_count();  // launches of the persistent MFMA GEMMs so far (tests assert the path taken)
 void gemm_note_launch();
@@ -240,7 +224,6 @@ void prefill_force_route(int kernel, int slices);  // zg_debug_prefill_linear: p
 // (attn_prefill.hip: bf16 matrix cores on exact plane splits; ws = fp32 workspace for the partials of split key ranges)
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, const float* k_cache_or_null,
                         const float* v_cache_or_null, int ctx, hipStream_t s);
-int launch_attn_prefill_f32(const float* qkv, bf16_t* out, int B, int P, int E, int H, hipStream_t s);  // the fp32-MFMA kernel it replaces (A/B)
 
 // GPT.sample tail: in-place softmax(logits / temp) per sequence + inverse-CDF draw with uniform u[b].
 int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s);
@@ -271,8 +254,6 @@ struct EmbedArgs {
     bf16_t* pl_out;          // optional planes of pl_g * x for the first Linear of the lock-step batch (GemvArgs.pl_in)
     const float* pl_g;
     unsigned* epoch;         // optional step counter behind the tagged hand-overs (GemvArgs.sk_tag): +1 when a step starts
-    unsigned long long* xg;  // two-stream decode (GemvArgs.xg): x leaves as (value, tag) granules, tag = (*epoch2 + 1) << 8 | 1,
-    unsigned* epoch2;        // and *epoch2 advances (the step counter of the graph this kernel opens)
     float* st_out;           // optional LayerNorm statistics by tile of x (GemvArgs.st_in): [8][n_embed / 16][2]
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
     unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
