@@ -264,9 +264,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
         // ---- phase A: the next tile's scores beside this tile's probabilities
         f32x16 sn, sm;
         if constexpr (WITH_S) s_tile(SLOT ^ 1, sn, sm);
-#ifdef ZG_ATTN_DBG_BAR2
-        __syncthreads();
-#endif
         const float mref = fmaxf(mrun, -1e30f);  // (all keys masked so far: 2^(-inf - mref) = 0, not NaN)
         float psum = 0.0f;
 #pragma unroll
@@ -284,17 +281,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
 #pragma unroll
             for (int p = 0; p < 3; ++p) pf[p][sp] = frag(w[0][p], w[1][p], w[2][p], w[3][p]);
         }
-#ifdef ZG_ATTN_SGB
-        if constexpr (WITH_S) {  // pin phase A's stream: one K-fragment read and ~6 vector instructions per MFMA
-#pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                if (k < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         // ---- phase B: O^T += V^T P^T beside the staging of the tiles in flight.  The lane's V fragment = keys 16 s' + 4 hl + {0..3, 8..11}
         // of head dimension l31 (+ 32).
         const char* vp = vring + SLOT * 3 * kVPlane + voff;
@@ -316,22 +302,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][PK[t]], pf[PQ[t]][sp], o1, 0, 0, 0);
             }
         }
-#ifdef ZG_ATTN_DBG_BAR
-        __syncthreads();
-#endif
         store_k(SLOT, kr);       // K(i + 2): the slot K(i) left in the previous tile's phase A
         store_v(SLOT ^ 1, vr);   // V(i + 1): the slot V(i - 1) left in the previous tile's phase B
         load_k(kt + 3, kr);
         load_v(kt + 2, vr);
-#ifdef ZG_ATTN_SGB
-#pragma unroll
-        for (int k = 0; k < 24; ++k) {  // phase B: one transposed V read and ~4 vector instructions per MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if constexpr (WITH_S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = sn[r] + sm[r];
