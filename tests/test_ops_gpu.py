@@ -134,7 +134,7 @@ def test_linear_wider_than_the_four_wave_gemm_arguments(zg):
     """in_features = 16384 at batch 16: rows of three planes (49152 elements) and 256 K-steps per plane are beyond what
     gemm_s4_kernel's packed arguments express — the Linear must fall through to the eight-wave GEMM instead of failing
     (the reference Linear has no size limit, src/ops.zig:21-46).  A ragged width, which only the four-wave kernel stores,
-    goes to the GEMV kernels, whose own bound (in_features <= 8192) then answers with ZG_ERR_UNSUPPORTED — loudly."""
+    goes to the GEMV kernels — in K chunks of 8192 (round 5; it answered ZG_ERR_UNSUPPORTED before)."""
     m, k, n = 16, 16384, 128
     w = synth.fill_normal(100 + n, n * k, 0, 0.02).reshape(n, k)
     b = synth.fill_normal(200 + n, n, 0, 0.05)
@@ -144,10 +144,24 @@ def test_linear_wider_than_the_four_wave_gemm_arguments(zg):
     ops.Linear(k, n, w, b).forward(x, y)
     assert zg.zg_debug_gemm_launches() == before + 1
     assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n}", scale_floor=2e-6)
-    from zig_gpt2_amd._lib import ZgError
-    with pytest.raises(ZgError) as e:
-        ops.Linear(k, 130, np.ascontiguousarray(np.resize(w, (130, k))), None).forward(x, z(m, 130))
-    assert e.value.code == -5
+    w130 = np.ascontiguousarray(np.resize(w, (130, k)))
+    y130 = z(m, 130)
+    ops.Linear(k, 130, w130, None).forward(x, y130)
+    assert zg.zg_debug_gemm_launches() == before + 1, "the ragged width must not take the MFMA path"
+    assert_ref_close(oracle.linear_forward(k, 130, w130, None, x), y130, f"Linear {m}x{k}x130 (K chunks)", scale_floor=2e-6)
+
+
+@pytest.mark.parametrize("m,k,n,bias", [(1, 8200, 37, True), (3, 12328, 70, True), (9, 20000, 16, False), (2, 16384, 2100, True)])
+def test_linear_wider_than_8192_runs_in_k_chunks(zg, m, k, n, bias):
+    """Linear.forward has no size limit (src/ops.zig:21-46): in_features beyond the 8192 the GEMV kernels hold in LDS runs as K chunks
+    (chunk 0 with the bias, later chunks through the residual epilogue onto the same rows; W in row blocks of 2048 for the 2100-row
+    case); batch 9 = two row groups."""
+    w = synth.fill_normal(100 + n, n * k, 0, 0.02).reshape(n, k)
+    b = synth.fill_normal(200 + n, n, 0, 0.05) if bias else None
+    x = synth.fill_normal(300 + m, m * k, 0, 1.0).reshape(m, k)
+    y = z(m, n)
+    ops.Linear(k, n, w, b).forward(x, y)
+    assert_ref_close(oracle.linear_forward(k, n, w, b, x), y, f"Linear {m}x{k}x{n} (K chunks)", scale_floor=2e-6)
 
 
 def test_registered_mirror_is_never_used_for_activations(zg):

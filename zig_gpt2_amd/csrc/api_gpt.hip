@@ -958,7 +958,7 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
     if (mat && g->wt == WT_F32 && y.c_attn_p) {  // exact bf16 planes of the fp32 matrix for the whole-prompt GEMMs
         bf16_t* pl = slot == ZG_C_ATTN_W ? y.c_attn_p : slot == ZG_C_PROJ_W ? y.c_proj_p : slot == ZG_C_FC_W ? y.c_fc_p : y.mlp_proj_p;
         // plane-major [3][out][in]: the matrix as ONE row of out * in elements
-        ZG_REQUIRE(n < ((size_t)1 << 31), ZG_ERR_SHAPE, "weight matrix of %zu elements", n);
+        ZG_REQUIRE(n <= (size_t)2147483647 / 3, ZG_ERR_SHAPE, "weight matrix of %zu elements", n);  // (split3_kernel indexes 3 n in int)
         ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), 1, (int)n, pl, ctx().stream));
         ZG_HIP(hipStreamSynchronize(ctx().stream));
     }

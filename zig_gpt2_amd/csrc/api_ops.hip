@@ -198,6 +198,52 @@ static int linear_device(size_t in_f, size_t out_f, const float* w, const float*
     return ZG_OK;
 }
 
+// Linear.forward has no size limit (src/ops.zig:21-46).  The GEMV kernels keep a batch of input rows in LDS, which ends at
+// in_features = 8192: a wider Linear runs as K chunks of <= 8192 — chunk 0 computes y = bias + W[:, chunk] x[chunk], every
+// later chunk adds its product to y (the residual epilogue, y aliasing the residual) — over contiguous copies of the chunk's
+// columns of W (blocks of rows, so that the copy stays a few tens of MB of the staging arena) and of x.  fp32 throughout; the
+// partial sums of a row meet in chunk order.
+static int linear_device_wide(Call& call, size_t in_f, size_t out_f, const float* w, const float* bias, const float* x, size_t m, float* y) {
+    hipStream_t s = call.stream();
+    if (in_f <= 8192) return linear_device(in_f, out_f, w, bias, x, m, y, s);
+    if (m == 0 || out_f == 0) return ZG_OK;
+    const size_t kc_max = 8192;
+    size_t rows = (((size_t)64 << 20) / (kc_max * sizeof(float)));  // rows of W per block: 64 MiB of chunk copy
+    if (rows > out_f) rows = out_f;
+    float *wc, *xc;
+    ZG_TRY(call.scratch(rows * kc_max, &wc));
+    ZG_TRY(call.scratch(8 * kc_max, &xc));
+    for (size_t m0 = 0; m0 < m; m0 += 8) {
+        const size_t mb = m - m0 < 8 ? m - m0 : 8;
+        for (size_t k0 = 0; k0 < in_f; k0 += kc_max) {
+            const size_t kc = in_f - k0 < kc_max ? in_f - k0 : kc_max;
+            ZG_HIP(hipMemcpy2DAsync(xc, kc * 4, x + m0 * in_f + k0, in_f * 4, kc * 4, mb, hipMemcpyDeviceToDevice, s));
+            for (size_t n0 = 0; n0 < out_f; n0 += rows) {
+                const size_t nb = out_f - n0 < rows ? out_f - n0 : rows;
+                ZG_HIP(hipMemcpy2DAsync(wc, kc * 4, w + n0 * in_f + k0, in_f * 4, kc * 4, nb, hipMemcpyDeviceToDevice, s));
+                GemvArgs a{};
+                a.W = wc;
+                a.bias = (k0 == 0 && bias) ? bias + n0 : nullptr;
+                a.N = (int)nb;
+                a.K = (int)kc;
+                a.M = (int)mb;
+                a.prologue = PRO_NONE;
+                a.epilogue = k0 == 0 ? EPI_STORE : EPI_RESIDUAL;
+                a.x = xc;
+                a.x_stride = (int)kc;
+                a.y = y + m0 * out_f + n0;
+                a.y_stride = (int)out_f;
+                a.resid = k0 == 0 ? nullptr : a.y;
+                a.resid_stride = (int)out_f;
+                a.zero = ctx().d_zero;
+                const int grid = gemv_plan(a);
+                ZG_TRY(launch_gemv(a, WT_F32, grid, s));
+            }
+        }
+    }
+    return ZG_OK;
+}
+
 static int attn_core(const float* q, const float* k, const float* v, long stride_b, long stride_h,
                      long stride_t, size_t batch, size_t n_heads, size_t seq_len, float* out, hipStream_t s) {
     Ctx& c = ctx();
@@ -358,7 +404,7 @@ int zg_linear_forward(size_t in_features, size_t out_features, const float* weig
     if (linear_mfma_ok(in_features, out_features, batch, call.arena_left()))
         ZG_TRY(linear_mfma(call, in_features, out_features, w, b, x, batch, y));
     else
-        ZG_TRY(linear_device(in_features, out_features, w, b, x, batch, y, call.stream()));
+        ZG_TRY(linear_device_wide(call, in_features, out_features, w, b, x, batch, y));
     ZG_TRY(call.finish());
     guard.done = true;
     return ZG_OK;

@@ -254,7 +254,7 @@ __device__ __forceinline__ void prefill_gemm_body(const bf16_t* __restrict__ A, 
 #else
         const bool more = t + 1 < nt;
 #endif
-        const unsigned kill = more ? 0u : 0xC0000000u;
+        const unsigned kill = more ? 0u : 0x80000000u;  // (operands < 2 GiB: offset + kill never wraps, and lies past every descriptor's end)
         const char* cur = lds + ((t - t0) & 1) * kStageB;
         // 12 groups (16-k slice kk, plane p = 2, 1, 0: smallest plane first) of 2 NJ MFMAs.  The fragments of group g + 1 are
         // read IN FRONT of group g's MFMAs (two register sets, sched barriers pin the order): with one wave per SIMD nothing
@@ -682,9 +682,12 @@ int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, voi
         if (n_sl == 1 && epi == PF_GELU_SPLIT) return launch_gemm_s4_prefill(A, B, bias, C, M, N, K, nsplit, S4_SPLIT3, 1, nullptr, s);
         if (n_sl == 1 && epi == PF_QKV && qkv && ldc == N) return launch_gemm_s4_prefill(A, B, bias, C, M, N, K, nsplit, S4_QKV, 1, qkv, s);
     }
-    // (the operands are addressed through 32-bit buffer descriptors, and an offset of 3 << 30 must lie past their ends)
-    ZG_REQUIRE((size_t)M * kSplit * K * 2 < ((size_t)3 << 30) && (size_t)N * K * 2 < ((size_t)3 << 30), ZG_ERR_UNSUPPORTED,
-               "prefill gemm: operands of %d x %d x %d beyond 3 GiB", M, N, K);
+    // (the operands are addressed through 32-bit buffer descriptors; a piece is switched off by adding 2 GiB to its scalar offset,
+    // which must then lie past the descriptor's end without wrapping: operands < 2 GiB.  That a raw buffer access is range-checked
+    // on voffset + soffset — LLVM documents only voffset — is pinned on the hardware by tools/microbench/soffset_bounds_probe.hip,
+    // tests/test_hw_rules_gpu.py)
+    ZG_REQUIRE((size_t)M * kSplit * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 31), ZG_ERR_UNSUPPORTED,
+               "prefill gemm: operands of %d x %d x %d beyond 2 GiB", M, N, K);
     ZG_REQUIRE(nsplit == 2 || nsplit == kSplit || nsplit == kWeightPlanes, ZG_ERR_ARG, "prefill gemm: %d activation planes", nsplit);
     const PrefillQkv none{};
     switch (epi) {

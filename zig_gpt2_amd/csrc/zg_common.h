@@ -57,9 +57,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
 // upper mantissa bits — kept as a bf16-shaped upper half in one plane and the next 8 mantissa bits in a byte plane with the
 // same element index.  Relative error 2^-17 per element.  b24_round returns the 24 bits right-aligned.
 __device__ __forceinline__ uint32_t b24_round(float x) {
-    uint32_t b = __float_as_uint(x);
-    b += 0x7Fu + ((b >> 8) & 1u);
-    return b >> 8;
+    const uint32_t b = __float_as_uint(x);
+    uint32_t r = (b + 0x7Fu + ((b >> 8) & 1u)) >> 8;
+    // a finite value within 2^-17 of FLT_MAX must not round up to inf (0 x inf would poison masked positions, as the fp16 cache's
+    // clamp prevents): one ulp back.  inf / NaN inputs keep their class.
+    if ((r & 0x7F8000u) == 0x7F8000u && (b & 0x7F800000u) != 0x7F800000u) r -= 1u;
+    return r;
 }
 __device__ __forceinline__ void b24_store(void* cache, size_t lo_off, size_t elem, float x) {
     const uint32_t r = b24_round(x);
