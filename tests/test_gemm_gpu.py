@@ -84,7 +84,7 @@ def test_gemm_many_tiles_per_workgroup(zg, bn, wgs, out_bf16, monkeypatch):
     next tile's operands already in flight, odd K-step counts, ragged edges), both tile widths, both output types
     (the bf16 epilogue goes through an LDS image); repeated runs must agree bit for bit (race screen: a missing
     barrier behind the tile hand-over once showed up only with more than two tiles per workgroup)."""
-    monkeypatch.setenv("ZGPT2_GEMM_BN", str(bn))
+    monkeypatch.setenv("ZGPT2_GEMM_KERNEL", "s4" if bn == 192 else "p8:256")  # 192-wide tiles: the four-wave kernel; 256-wide: the eight-wave one
     monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
     m, n, k = 1100, 776, 320
     a = synth.fill_normal(7, m * k, 0.0, 1.0, bf16=True).reshape(m, k)

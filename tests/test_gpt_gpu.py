@@ -310,14 +310,14 @@ def test_steps_per_graph_do_not_change_tokens(zg, monkeypatch, steps):
 @pytest.mark.parametrize("name", ["tiny3", "nano-char"])
 def test_batched_weight_load_shapes_agree(zg, monkeypatch, name):
     """The batched Linears fetch weights as full lines through a transposing LDS slot and lm_head runs one wave per
-    tile; the fragment-shaped loads / the K-split lm_head remain as fall-backs (ZGPT2_NO_LINE_LOADS,
-    ZGPT2_NO_LM_WPT): same tokens either way, and both equal the oracle's."""
+    tile; the fragment-shaped loads / the K-split lm_head remain as fall-backs (ZGPT2_DECODE_PATHS_OFF
+    bits 16 / 32): same tokens either way, and both equal the oracle's."""
     cfg = synth.CONFIGS[name]
     w = synth.make_weights(cfg, seed=33, bf16=True)
     prompts = [synth.rand_tokens(330 + b, 1 + b % 3, cfg.vocab_size) for b in range(5)]
     n = min(cfg.context_size, 40)
     outs = []
-    for env in ({}, {"ZGPT2_NO_LINE_LOADS": "1", "ZGPT2_NO_LM_WPT": "1"}):
+    for env in ({}, {"ZGPT2_DECODE_PATHS_OFF": "48"}):  # bits 16 + 32: fragment-shaped loads, the K-split lm_head
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         m = zgpt.GPT(cfg, batch=5, prefill=False)

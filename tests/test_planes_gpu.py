@@ -1,7 +1,7 @@
 """Lock-step batch with bf16 weights: the activation planes between the kernels of a Block (GemvArgs.pl_in / pl_out,
 zg_common.h plane_elem), the four-wave plane-fed Linear, the attention-side head merge and the tagged hand-overs —
-against the CPU oracle, and against the paths they replace (ZGPT2_NO_PLANES / ZGPT2_NO_PL4 / ZGPT2_NO_TAGS /
-ZGPT2_NO_TILE_STATS switch them off per handle), which stay in the library as the route for shapes the new kernels do not take.
+against the CPU oracle, and against the paths they replace (the bits of ZGPT2_DECODE_PATHS_OFF
+switch them off per handle), which stay in the library as the route for shapes the new kernels do not take.
 
 Tolerance: greedy ids against independent oracle generations (golden_io.assert_greedy_ids_match: identical unless the
 oracle's own top-2 margin is inside the north_star bound); between the variants only the summation order of fp32 partial sums differs: 1e-5 of the logit scale, greedy ids identical."""
@@ -16,14 +16,14 @@ from zig_gpt2_amd.synth import GPTConfig
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"default": {}, "tickets": {"ZGPT2_NO_TAGS": "1"}, "16-wave": {"ZGPT2_NO_PL4": "1"},
-            "16-wave tickets": {"ZGPT2_NO_PL4": "1", "ZGPT2_NO_TAGS": "1"}, "LDS planes": {"ZGPT2_NO_PLANES": "1"},
-            "statistics from x": {"ZGPT2_NO_TILE_STATS": "1"}}
+# ZGPT2_DECODE_PATHS_OFF bits (zg_common.h): 1 planes between kernels, 2 the four-wave Linear, 4 tagged hand-overs, 8 tile statistics
+VARIANTS = {"default": {}, "tickets": {"ZGPT2_DECODE_PATHS_OFF": "4"}, "16-wave": {"ZGPT2_DECODE_PATHS_OFF": "2"},
+            "16-wave tickets": {"ZGPT2_DECODE_PATHS_OFF": "6"}, "LDS planes": {"ZGPT2_DECODE_PATHS_OFF": "1"},
+            "statistics from x": {"ZGPT2_DECODE_PATHS_OFF": "8"}}
 
 
 def run_variant(monkeypatch, env, cfg, w, batch, prompts, n_steps, **kw):
-    for k in ("ZGPT2_NO_TAGS", "ZGPT2_NO_PL4", "ZGPT2_NO_PLANES", "ZGPT2_NO_TILE_STATS"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("ZGPT2_DECODE_PATHS_OFF", raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     m = zgpt.GPT(cfg, batch=batch, **kw)
@@ -86,7 +86,7 @@ def test_fp16_cache_with_planes(zg, monkeypatch):
     w = synth.make_weights(cfg, seed=5, bf16=True)
     prompts = [synth.rand_tokens(50 + b, 2, cfg.vocab_size) for b in range(4)]
     a, la = run_variant(monkeypatch, {}, cfg, w, 4, prompts, cfg.context_size, kv_f16=True)
-    b, lb = run_variant(monkeypatch, {"ZGPT2_NO_PLANES": "1"}, cfg, w, 4, prompts, cfg.context_size, kv_f16=True)
+    b, lb = run_variant(monkeypatch, {"ZGPT2_DECODE_PATHS_OFF": "1"}, cfg, w, 4, prompts, cfg.context_size, kv_f16=True)
     assert np.array_equal(a, b)
     assert np.abs(la - lb).max() <= 2e-4 * np.abs(la).max()
 

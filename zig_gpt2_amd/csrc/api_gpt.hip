@@ -825,7 +825,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         }
     }
     g->pl_on = false;
-    if (g->wt == WT_BF16 && batch >= 2 && !env_int("ZGPT2_NO_PLANES", 0)) {  // all three plane-fed Linears on the matrix-core path?
+    if (g->wt == WT_BF16 && batch >= 2 && !(decode_paths_off() & 1)) {  // all three plane-fed Linears on the matrix-core path?
         const zg_layer& y = g->layers[0];
         GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, 0);
         a1.prologue = PRO_LAYERNORM;
@@ -846,10 +846,10 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         g->pl_on = c.n_embed % 32 == 0 && gemv_planes_ok(a1, g->wt) && gemv_planes_ok(a3, g->wt) && gemv_planes_ok(a4, g->wt) &&
                    gemv_planes_ok(a5, g->wt);
     }
-    g->tags_on = g->pl_on && !env_int("ZGPT2_NO_TAGS", 0);
+    g->tags_on = g->pl_on && !(decode_paths_off() & 4);
     g->spin_limit = (unsigned)env_int("ZGPT2_TAG_SPIN_LIMIT", 1 << 20);
     g->st_on = false;
-    if (g->pl_on && !env_int("ZGPT2_NO_TILE_STATS", 0) && c.n_embed % 16 == 0 && c.n_embed / 16 <= 128) {
+    if (g->pl_on && !(decode_paths_off() & 8) && c.n_embed % 16 == 0 && c.n_embed / 16 <= 128) {
         // every producer and consumer of x must be the four-wave kernel
         const zg_layer& y = g->layers[0];
         GemvArgs a1 = base_gemv(g, y.c_attn_w, y.c_attn_b, 3 * c.n_embed, c.n_embed, 0);

@@ -11,6 +11,11 @@ namespace zg {
 
 static thread_local char g_err[512] = "";
 
+int decode_paths_off() {
+    const char* e = getenv("ZGPT2_DECODE_PATHS_OFF");
+    return e ? atoi(e) : 0;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -499,8 +499,7 @@ int launch_p8(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int 
         raised = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = (N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
-    const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
-    int gw = gw_env > 0 ? gw_env : 8;
+    int gw = 8;  // tile-order band width (sweep 1 .. 16: profiles/NOTEBOOK.md)
     if (gw > tiles_n) gw = tiles_n;
     const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;  // tests: few workgroups, many tiles each
     const int cus = cus_env > 0 ? cus_env : 256;
@@ -554,7 +553,8 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     }
     // tile width: the one that wastes fewer CU-rounds (M = 8192, N = 3072: 512 tiles of 256 x 192 = 2.0 per CU
     // against 384 tiles of 256 x 256 = two rounds with half the chip idle in the second)
-    const int bn_env = getenv("ZGPT2_GEMM_BN") ? atoi(getenv("ZGPT2_GEMM_BN")) : 0;
+    const char* kk = getenv("ZGPT2_GEMM_KERNEL");  // test / measurement hook: s4 | p8 | p8:192 | p8:256
+    const int bn_env = (kk && !strcmp(kk, "p8:192")) ? 192 : (kk && !strcmp(kk, "p8:256")) ? 256 : 0;
     auto cost = [&](int bn) {
         const long tiles = (long)((M + 255) / 256) * ((N + bn - 1) / bn);
         return ((tiles + 255) / 256) * bn;
@@ -568,8 +568,7 @@ int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void
     // choice (its 256-wide instantiation does not fit the register file without spills yet), the eight-wave one below
     // for 256-wide tiles.  ZGPT2_GEMM_KERNEL=p8 / s4 forces one (s4 then always with 192-wide tiles).  (The third generation —
     // a tile's epilogue under the next tile's main loop, bitwise equal and slower — lives in tools/experiments/gemm_ov.hip.)
-    const char* kk = getenv("ZGPT2_GEMM_KERNEL");
-    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strcmp(kk, "p8");
+    const bool force_s4 = kk && !strcmp(kk, "s4"), force_p8 = kk && !strncmp(kk, "p8", 2);
     // The four-wave kernel packs its arguments (gemm_s4_args_ok: lda / ldb < 65536, K < 16384 per plane, <= 6 plane pairs);
     // a shape beyond that runs on the eight-wave kernel — unless it is ragged, which only the four-wave kernel stores.
     const bool s4_ok = gemm_s4_args_ok(pl, ldc);

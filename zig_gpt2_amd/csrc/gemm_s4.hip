@@ -865,8 +865,7 @@ int launch_s4_kind(const bf16_t* A, const bf16_t* B, const float* bias, void* C,
         raised = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = (N + P::BN - 1) / P::BN, n_tiles = tiles_m * tiles_n * n_sl;
-    const int gw_env = getenv("ZGPT2_GW") ? atoi(getenv("ZGPT2_GW")) : 0;
-    int gw = gw_env > 0 ? gw_env : 8;
+    int gw = 8;  // tile-order band width (sweep 1 .. 16: profiles/NOTEBOOK.md)
     if (gw > tiles_n) gw = tiles_n;
     const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;  // tests: few workgroups, many tiles each
     const int cus = cus_env > 0 ? cus_env : 256;

@@ -332,13 +332,13 @@ __device__ __forceinline__ void store_split4(char* planes, int S, int m, int k, 
 
 // ---- host-side shape tests shared by the launchers and the planner
 inline int lm_wpt_steps(const GemvArgs& a) {
-    const int off = getenv("ZGPT2_NO_LM_WPT") ? atoi(getenv("ZGPT2_NO_LM_WPT")) : 0;  // read per call: tests flip it between handles
+    const int off = decode_paths_off() & 32;  // read per call: tests flip it between handles
     if (off || a.epilogue != EPI_ARGMAX || a.prologue != PRO_LAYERNORM || a.M < 2 || a.M > kMfmaRows || a.K % 32 != 0) return 0;
     const int ns = a.K / 32;
     return (ns == 12 || ns == 24 || ns == 32) ? ns : 0;
 }
 inline int lm_wpt_tiles_per_wg() {  // a multiple of the four waves
-    static const int v = getenv("ZGPT2_LM_WPT_TILES") ? atoi(getenv("ZGPT2_LM_WPT_TILES")) : 8;
+    constexpr int v = 8;  // (sweep: profiles/round4_lm_head_tiles_sweep.txt)
     return v >= 4 ? (v / 4) * 4 : 4;
 }
 
@@ -350,7 +350,7 @@ inline size_t gemv_mfma_lds(int K, int nw, bool alias_partial = false, bool line
 }
 // full-line weight loads (LINE instantiations): whole pairs of 32-k steps and room for one 2-KiB slot per wave
 inline bool gemv_mfma_line(int K, int nw, bool alias_partial, bool gpl = false) {
-    const int off = getenv("ZGPT2_NO_LINE_LOADS") ? atoi(getenv("ZGPT2_NO_LINE_LOADS")) : 0;  // read per call: tests flip it between handles
+    const int off = decode_paths_off() & 16;  // read per call: tests flip it between handles
     return !off && !alias_partial && K % 64 == 0 && gemv_mfma_lds(K, nw, false, true, gpl) <= 160 * 1024;
 }
 
@@ -362,7 +362,7 @@ inline bool gemv_mfma_alias(const GemvArgs& a) {
 // Plane-fed Linears as four-wave workgroups (gemv_pl4_kernel): one tile per workgroup, whole 64-k pairs, at most five
 // pairs per wave and slice (K <= 1280 per slice: every GPT-2 size but XL, which stays on the 16-wave kernel).
 inline int pl4_pairs(const GemvArgs& a) {
-    const int off = getenv("ZGPT2_NO_PL4") ? atoi(getenv("ZGPT2_NO_PL4")) : 0;  // read per call: tests flip it between handles
+    const int off = decode_paths_off() & 2;  // read per call: tests flip it between handles
     if (off || a.pl_in == nullptr || a.epilogue == EPI_ARGMAX || a.rows_per_wave != 1) return 0;
     if (a.N > 0xffff || (a.prologue == PRO_LAYERNORM && a.x_stride != a.K) || (a.epilogue == EPI_RESIDUAL && a.resid_stride != a.N)) return 0;
     if (a.st_in != nullptr && a.K / 16 > 128) return 0;

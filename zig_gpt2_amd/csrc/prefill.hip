@@ -541,8 +541,6 @@ int launch_prefill_gemm_np(const bf16_t* A, const bf16_t* B, const float* bias, 
     if (n_sp > nt / 3) n_sp = nt / 3;
     if (n_sp < 1) n_sp = 1;
     while (n_sp > 1 && (size_t)n_sp * M * N > ws_floats) --n_sp;
-    static const int force = getenv("ZGPT2_PF_SPLITK") ? atoi(getenv("ZGPT2_PF_SPLITK")) : 0;
-    if (force > 0) n_sp = force;
     const unsigned xg = xcd_grid_rows(tiles_m, tiles_n, (size_t)BM * (K / (n_sp > 1 && ws ? n_sp : 1)) * 2 * nsplit,
                                       (size_t)BN * NS * (K / (n_sp > 1 && ws ? n_sp : 1)) * 2);
     if (n_sp <= 1 || !ws) {

@@ -14,6 +14,11 @@ void set_error(const char* fmt, ...);
 // it as the roofline's kernel symbol instead of a hand-kept table).
 void note_kernel(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
+// Test hook ZGPT2_DECODE_PATHS_OFF (bit mask, read per call): the lock-step decode's newer paths switched off so that the paths
+// they replaced — still the route of shapes the newer kernels do not take — can be held to the same tokens (tests/test_planes_gpu.py):
+// 1 activation planes between kernels, 2 the four-wave plane-fed Linear, 4 tagged hand-overs (tickets instead), 8 LayerNorm
+// statistics by tile, 16 line-shaped weight loads, 32 the wave-per-tile lm_head.
+int decode_paths_off();
 
 #define ZG_HIP(expr)                                                         \
     do {                                                                     \
