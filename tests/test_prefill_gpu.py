@@ -71,6 +71,24 @@ def test_prefill_linears_on_the_persistent_four_wave_gemm(zg, monkeypatch, name,
     m.close()
 
 
+def test_prefill_c_attn_hands_half_tiles_over_between_workgroups(zg, monkeypatch):
+    """1.5 rounds of c_attn tiles (eight 1023-token prompts at 124M: 384 tiles on 256 CUs) run as whole tiles plus K halves of the
+    last half round on ALL workgroups, the producer's accumulators handed to its consumer through memory (gemm_s4.hip, SK).
+    Small stand-in with the same geometry: nano-char, 4 x 256 tokens = 4 x 6 tiles on 16 workgroups (16 whole + 8 shared)."""
+    monkeypatch.setenv("ZGPT2_PF_S4_TILES", "1")
+    monkeypatch.setenv("ZGPT2_GEMM_WGS", "16")
+    cfg = synth.CONFIGS["nano-char"]
+    m, w = make(cfg, 77, batch=4)
+    n = 256
+    toks = np.stack([synth.rand_tokens(770 + b, n, cfg.vocab_size) for b in range(4)])
+    for rep in range(3):  # (the flags carry the launch's epoch: repeated passes must not see an earlier pass's hand-over)
+        lg = m.prefill(toks)
+        for b in range(4):
+            lg_ref = oracle.GPT(cfg, w).forced_logits(toks[b], n - 1)
+            assert_model_close(lg_ref[0], lg[b], f"stream-K c_attn row {b} pass {rep}")
+    m.close()
+
+
 @pytest.mark.parametrize("kv_f16", [False, True])
 def test_prefill_batched_rows_are_independent(zg, kv_f16):
     cfg = synth.CONFIGS["tiny"]

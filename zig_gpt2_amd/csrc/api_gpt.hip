@@ -55,6 +55,9 @@ struct zg_gpt {
     // whole-prompt (prefill) scratch, rows = batch * ctx: x fp32 [E], qkv fp32 [3E], split bf16 [kSplit E] and [kSplit 4E]
     float *pf_x, *pf_qkv, *pf_ws;
     size_t pf_ws_floats;
+    unsigned* sk_flags;   // stream-K hand-over of the c_attn GEMM (PrefillQkv.sk_*): 512 flag words, zeroed at create
+    unsigned sk_epoch;
+    bool sk_used;         // a stream-K launch since the last check of gemm_s4_fault
     bf16_t *pf_a, *pf_h;
     // lock-step batch with bf16 weights: activation planes between the kernels of a Block (GemvArgs.pl_in / pl_out):
     // xp = planes of g * x for the next LayerNorm-fed Linear [48 E bytes], hp = planes of gelu(c_fc) [48 * 4E bytes]
@@ -190,6 +193,9 @@ void carve(zg_gpt* g, char* base) {
     g->pf_ctl = (PfCtl*)P(sizeof(PfCtl));
     g->pf_jobs = (PfJob*)P((size_t)g->pf_njobs * sizeof(PfJob));
     g->pf_x = g->pf_qkv = g->pf_ws = nullptr;
+    g->sk_flags = nullptr;
+    g->sk_epoch = 0;
+    g->sk_used = false;
     g->pf_a = g->pf_h = nullptr;
     g->pf_ws_floats = 0;
     if (!(g->flags & ZG_GPT_NO_PREFILL)) {
@@ -201,6 +207,7 @@ void carve(zg_gpt* g, char* base) {
         // split-K partials of the prompt GEMMs; fp32 weights: three weight-plane passes of [B ctx, 4 E] at the least
         g->pf_ws_floats = g->wt == WT_BF16 ? (size_t)(16u << 20) : std::max((size_t)(16u << 20), 3 * B * C * 4 * E);
         g->pf_ws = (float*)P(g->pf_ws_floats * 4);
+        g->sk_flags = (unsigned*)P(2048);
     }
     g->arena_bytes = (cv.off + 255) & ~(size_t)255;
 }
@@ -533,7 +540,14 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
         const zg_layer& y = g->layers[l];
         // pf_a holds split(ln_1(x)) here: from the line above or from the tail of the previous Block's last GEMM
         // c_attn with the cache append of ops.zig:152-157 in its epilogue
-        const PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_mode, y.k_cache, y.v_cache, g->batch * C * E * 2};
+        PrefillQkv qa{(int)P, iE, (int)H, (int)C, g->kv_mode, y.k_cache, y.v_cache, g->batch * C * E * 2};
+        if (!f32w && g->sk_flags != nullptr) {  // (the persistent GEMM may hand half tiles over between workgroups: gemm_s4.hip SK)
+            qa.sk_ws = g->pf_ws;
+            qa.sk_ws_bytes = g->pf_ws_floats * 4;
+            qa.sk_flags = g->sk_flags;
+            qa.sk_epoch = ++g->sk_epoch;
+            g->sk_used = true;
+        }
         ZG_TRY(launch_prefill_gemm(g->pf_a, f32w ? y.c_attn_p : (const bf16_t*)y.c_attn_w, y.c_attn_b, g->pf_qkv, M, 3 * iE, iE, 3 * iE, PF_QKV,
                                    g->pf_ws, g->pf_ws_floats, nullptr, s, &qa, np));
         if (l + 1 == L && !last_block_full) break;
@@ -558,6 +572,15 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
 // call).  The word lives in pinned host memory the kernels store to directly: reading it costs no copy and no second
 // synchronisation.  PRECONDITION: the stream has been drained since the steps in question.
 int check_fault(zg_gpt* g) {
+    if (g->sk_used) {  // a whole-prompt pass may have handed half tiles over inside gemm_s4: did a consumer give up waiting?
+        g->sk_used = false;
+        unsigned f = 0;
+        ZG_TRY(gemm_s4_fault(&f));
+        if (f) {
+            set_error("a half-tile hand-over of the whole-prompt c_attn GEMM timed out: results discarded");
+            return ZG_ERR_HIP;
+        }
+    }
     if (!g->tags_on) return ZG_OK;
     volatile unsigned* f = g->fault;
     if (*f == 0) return ZG_OK;
@@ -1105,7 +1128,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
                                   is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     }
     ZG_HIP(hipStreamSynchronize(s));
-    return ZG_OK;
+    return check_fault(g);
 }
 
 int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens) {

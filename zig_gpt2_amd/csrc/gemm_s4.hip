@@ -30,6 +30,7 @@ namespace zg {
 // constant 100 MHz clock (s_memrealtime: wall time inside the launch, whatever the shader clock does); [1025 ..] workgroup 0's phase
 // stamps (shader clock): start, prologue done, then {main loop done, epilogue done} per tile
 __device__ unsigned long long g_s4_stamps[1 + 4 * 256 + 16];
+__device__ unsigned g_s4_fault;  // a stream-K consumer ran out of polls (gemm_s4_fault())
 
 namespace {
 
@@ -139,6 +140,20 @@ __device__ __forceinline__ void acc_read16(float (&v)[16]) {  // the 16 register
     acc_read8<BASE>(v);
     acc_read8<BASE + 8>(v + 8);
 }
+template <int BASE>
+__device__ __forceinline__ void acc_write16(const u32x4 (&v)[4]) {  // sixteen accumulator registers from four loaded quads (SK)
+    asm volatile(
+        "v_accvgpr_write_b32 a[%c16], %0\n\tv_accvgpr_write_b32 a[%c17], %1\n\tv_accvgpr_write_b32 a[%c18], %2\n\tv_accvgpr_write_b32 a[%c19], %3\n\t"
+        "v_accvgpr_write_b32 a[%c20], %4\n\tv_accvgpr_write_b32 a[%c21], %5\n\tv_accvgpr_write_b32 a[%c22], %6\n\tv_accvgpr_write_b32 a[%c23], %7\n\t"
+        "v_accvgpr_write_b32 a[%c24], %8\n\tv_accvgpr_write_b32 a[%c25], %9\n\tv_accvgpr_write_b32 a[%c26], %10\n\tv_accvgpr_write_b32 a[%c27], %11\n\t"
+        "v_accvgpr_write_b32 a[%c28], %12\n\tv_accvgpr_write_b32 a[%c29], %13\n\tv_accvgpr_write_b32 a[%c30], %14\n\tv_accvgpr_write_b32 a[%c31], %15"
+        :
+        : "v"(v[0][0]), "v"(v[0][1]), "v"(v[0][2]), "v"(v[0][3]), "v"(v[1][0]), "v"(v[1][1]), "v"(v[1][2]), "v"(v[1][3]), "v"(v[2][0]), "v"(v[2][1]),
+          "v"(v[2][2]), "v"(v[2][3]), "v"(v[3][0]), "v"(v[3][1]), "v"(v[3][2]), "v"(v[3][3]), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3),
+          "i"(BASE + 4), "i"(BASE + 5), "i"(BASE + 6), "i"(BASE + 7), "i"(BASE + 8), "i"(BASE + 9), "i"(BASE + 10), "i"(BASE + 11), "i"(BASE + 12),
+          "i"(BASE + 13), "i"(BASE + 14), "i"(BASE + 15)
+        : ZG_ACC_CLOBBERS);
+}
 // A tile starts at its bias (the reference pre-fills the output with the bias, src/ops.zig:24-29).  The four 32 x 32 tiles of
 // one column tile j share the bias pattern of their 16 registers: it goes into the scratch accumulator a[192:207] once and
 // four MFMAs of zero operands copy it (0 x 0 + C; destination and C of an MFMA must both be accumulator registers) — on
@@ -191,7 +206,7 @@ __device__ __forceinline__ void read_b_all(bf16x8 (&fb)[4][NT], const unsigned (
 //   S4_SPLIT3   bias + GELU, then the exact three-term bf16 split as planes C[M][3N] = [hi | mid | lo]  (src/main.zig:79-80 feeding
 //               the next Linear's A operand)
 
-template <int NT, int KIND, bool GELU, bool OUT_BF16>
+template <int NT, int KIND, bool GELU, bool OUT_BF16, bool SK = false>
 __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          const float* __restrict__ bias, void* __restrict__ C, int M, int N,
                                                          unsigned p0, unsigned p1, unsigned p2, unsigned p3, const PrefillQkv qa) {
@@ -226,8 +241,38 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     const int gx = G / nx + (xcd < G % nx ? 1 : 0);
     const int q8 = n_tiles / nx, r8 = n_tiles % nx;
     const int t_begin = xcd * q8 + min(xcd, r8), t_end = t_begin + q8 + (xcd < r8 ? 1 : 0);
-    int idx = t_begin + loc;
-    if (idx >= t_end) return;
+    // The workgroup's work items: item k is tile t_begin + loc + k gx of its XCD's range.  SK (stream-K hand-over, S4_QKV when the
+    // tiles are 1.5 rounds of the workgroups — c_attn of eight 1023-token prompts: 384 tiles on 256 CUs, the second round half
+    // empty): G workgroups, R G + G / 2 tiles.  Every workgroup walks R whole tiles and HALF of one of the last G / 2: the K-steps
+    // [0, kpp / 2) of every plane (the producer: even place in its XCD, item 0 — it then spills its 192 accumulators per lane to
+    // sk_ws and raises a per-wave flag) or [kpp / 2, kpp) (the consumer: odd place — dispatched behind its producer — last item:
+    // its accumulators START at the producer's partial, which left more than a whole tile earlier, and it runs the epilogue).
+    int it = 0;
+    const int sk_R = SK ? tmn / G : 0, sk_gx = G >> 3;  // (SK: G % 16 == 0, tmn = sk_R G + G / 2: the launcher's conditions)
+    const bool sk_cons = SK && (loc & 1);
+    const int sk_sh = xcd * (sk_gx >> 1) + (loc >> 1);  // which of the G / 2 shared tiles
+    auto item = [&](int k, int& tile, int& half, int& role) {  // role 0 whole tile, 1 producer half, 2 consumer half; false: no item k
+        if constexpr (!SK) {
+            tile = t_begin + loc + k * gx;
+            half = 0;
+            role = 0;
+            return tile < t_end;
+        } else {
+            if (k > sk_R) return false;
+            if (sk_cons ? k == sk_R : k == 0) {
+                tile = sk_R * G + sk_sh;
+                half = sk_cons ? 1 : 0;
+                role = sk_cons ? 2 : 1;
+            } else {
+                tile = xcd * (sk_R * sk_gx) + loc + (sk_cons ? k : k - 1) * sk_gx;
+                half = 0;
+                role = 0;
+            }
+            return true;
+        }
+    };
+    int idx, half_cur = 0, role_cur = 0;
+    if (!item(0, idx, half_cur, role_cur)) return;
     const bool stamp = (dbg & 256) && wave == 0 && bid < 256;
     unsigned long long t_start = 0, w_start = 0;
     int n_phase = 0;
@@ -280,7 +325,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
 
     // ---- K-steps walk the plane pairs: step kt = pair * kpp + kk multiplies A plane pa[pair] with B plane pb[pair]
     const int kpp = pl.kpp;                                   // K-steps per plane (the plane stride of both operands)
-    const int kps = KIND == S4_PARTIAL ? kpp / n_sl : kpp;    // ... and those one tile walks
+    const int kps_full = KIND == S4_PARTIAL ? kpp / n_sl : kpp;  // ... and those one tile walks (SK: a half item walks kpp / 2)
+    int kps = (SK && role_cur != 0) ? kpp >> 1 : kps_full;
     int pi_cur = 0, kk_cur = 0;
     int tm, tn, sl = 0;
     auto locate = [&](int i, int& tm_, int& tn_, int& sl_) {  // the tile list: slice-major, then the banded order
@@ -291,16 +337,19 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         tile_of(i, tiles_m, tiles_n, gw, tm_, tn_);
     };
     locate(idx, tm, tn, sl);
-    const unsigned strideA = 256u * lda2, strideB = (unsigned)P::BN * ldb2, strideK = (unsigned)kps * 128u;
-    unsigned curA = (unsigned)tm * strideA + (unsigned)sl * strideK, curB = (unsigned)tn * strideB + (unsigned)sl * strideK;
+    const unsigned strideA = 256u * lda2, strideB = (unsigned)P::BN * ldb2, strideK = (unsigned)kps_full * 128u;
+    const unsigned halfK = (unsigned)(kpp >> 1) * 128u;  // SK: where the consumer's half of a plane begins
+    unsigned curA = (unsigned)tm * strideA + (unsigned)sl * strideK + (unsigned)half_cur * halfK;
+    unsigned curB = (unsigned)tn * strideB + (unsigned)sl * strideK + (unsigned)half_cur * halfK;
     int m0 = tm * 256, n0 = tn * P::BN;
     constexpr unsigned kOob = 0x80000000u;  // tile base of "no next tile": every lane out of range -> zero fill
     unsigned nxtA = kOob, nxtB = kOob;
-    int nidx = idx + gx, ntm = 0, ntn = 0, nsl = 0;
-    if (nidx < t_end) {
+    int nidx = 0, ntm = 0, ntn = 0, nsl = 0, half_nxt = 0, role_nxt = 0;
+    bool has_nxt = item(1, nidx, half_nxt, role_nxt);
+    if (has_nxt) {
         locate(nidx, ntm, ntn, nsl);
-        nxtA = (unsigned)ntm * strideA + (unsigned)nsl * strideK;
-        nxtB = (unsigned)ntn * strideB + (unsigned)nsl * strideK;
+        nxtA = (unsigned)ntm * strideA + (unsigned)nsl * strideK + (unsigned)half_nxt * halfK;
+        nxtB = (unsigned)ntn * strideB + (unsigned)nsl * strideK + (unsigned)half_nxt * halfK;
     }
     auto ahead = [&](int d) {  // K-step t + d of the stream (d <= 2 <= kps); runs on into the next tile
         int kk = kk_cur + d, pi = pi_cur;
@@ -523,7 +572,58 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // ---- epilogue of one tile, straight from the registers: lane (l31, hh) holds output row l31 of each 32 x 32
     // tile and columns 8 g + 4 hh + {0..3} (register 4 g + e).  bf16: v_permlane32_swap makes 8 consecutive
     // columns (16 B) per lane out of the two half-waves' runs of 4.
+    // ---- SK: the producer's half tile leaves as raw accumulators, [shared tile][wave][48 register quads][lane] x 16 B, write-
+    // through; then, its stores drained, one flag word per wave = this launch's epoch (the consumer's wave w polls wave w's flag
+    // and loads exactly what that wave stored: no workgroup barrier on either side).  The poll is bounded: a consumer that
+    // ran out raises g_s4_fault and carries on (the host checks the word where it drains the stream).
+    auto sk_spill = [&]() {
+        if constexpr (SK) {
+            acc_settle();
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(qa.sk_ws, 0, (unsigned)(G >> 1) * 196608u, 0x00020000);
+            const unsigned base = (unsigned)(sk_sh * 4 + wave) * 49152u + (unsigned)lane * 16u;
+            static_for<12>([&](auto QT) {
+                constexpr int q = decltype(QT)::value;
+                float av[16];
+                acc_read16<16 * q>(av);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4v v4 = {av[4 * e], av[4 * e + 1], av[4 * e + 2], av[4 * e + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), rw, base + (unsigned)(q * 4 + e) * 1024u, 0, 16);
+                }
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also the next item's DMA pieces in flight: they are due anyway)
+            if (lane == 0) __hip_atomic_store(qa.sk_flags + sk_sh * 4 + wave, qa.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto sk_init_from_partial = [&]() {
+        if constexpr (SK) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(qa.sk_flags + sk_sh * 4 + wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != qa.sk_epoch) {
+                if (++spins > (1u << 22)) {
+                    if (lane == 0) g_s4_fault = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(qa.sk_ws, 0, (unsigned)(G >> 1) * 196608u, 0x00020000);
+            const unsigned base = (unsigned)(sk_sh * 4 + wave) * 49152u + (unsigned)lane * 16u;
+            static_for<12>([&](auto QT) {
+                constexpr int q = decltype(QT)::value;
+                u32x4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, base + (unsigned)(q * 4 + e) * 1024u, 0, 16);
+                acc_write16<16 * q>(v);
+            });
+            asm volatile("s_nop 7" ::: ZG_ACC_CLOBBERS);  // v_accvgpr_write -> MFMA source C
+        }
+    };
     auto epilogue = [&]() {
+        if (SK && role_cur == 1) {  // a producer's half tile: no epilogue, the accumulators go to its consumer
+            sk_spill();
+            if (has_nxt) init_acc_from_bias(tile_par ^ 1);
+            ZG_SB();
+            return;
+        }
         acc_settle();
         if (dbg & 4) {  // diagnostic: no epilogue at all (the accumulators just keep running)
             return;
@@ -752,7 +852,10 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                 }
             }
         });
-        if (idx + gx < t_end) init_acc_from_bias(tile_par ^ 1);  // the next tile starts at its bias row
+        if (has_nxt) {  // the next tile starts at its bias row — or, a consumer's half tile, at its producer's partial
+            if (SK && role_nxt == 2) sk_init_from_partial();
+            else init_acc_from_bias(tile_par ^ 1);
+        }
         if constexpr (NPEND > 0) {
             pend_row = row0;
             pend_col = col0;
@@ -762,19 +865,23 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     };
     auto next_tile = [&]() {
         idx = nidx;
+        ++it;
         m0 = ntm * 256;
         n0 = ntn * P::BN;
         sl = nsl;
+        half_cur = half_nxt;
+        role_cur = role_nxt;
+        if constexpr (SK) kps = role_cur != 0 ? kpp >> 1 : kps_full;
         tile_par ^= 1;
         curA = nxtA;
         curB = nxtB;
-        nidx = idx + gx;
         nxtA = kOob;
         nxtB = kOob;
-        if (nidx < t_end) {
+        has_nxt = item(it + 1, nidx, half_nxt, role_nxt);
+        if (has_nxt) {
             locate(nidx, ntm, ntn, nsl);
-            nxtA = (unsigned)ntm * strideA + (unsigned)nsl * strideK;
-            nxtB = (unsigned)ntn * strideB + (unsigned)nsl * strideK;
+            nxtA = (unsigned)ntm * strideA + (unsigned)nsl * strideK + (unsigned)half_nxt * halfK;
+            nxtB = (unsigned)ntn * strideB + (unsigned)nsl * strideK + (unsigned)half_nxt * halfK;
             fetch_bias(ntn * P::BN, tile_par ^ 1);  // a whole tile ahead of its use (its buffer was last read before this tile began)
         }
     };
@@ -793,7 +900,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // [B of t + 2, A half 1 of t + 1, A half 0 of t + 2]; before K-step 0 that is [B 0, A0 0] and [B 1, A1 0, A0 1].
     {
         fetch_bias(n0, 0);
-        if (nidx < t_end) fetch_bias(ntn * P::BN, 1);
+        if (has_nxt) fetch_bias(ntn * P::BN, 1);
         const Ahead s0 = ahead(0);
         s1 = ahead(1);
         s2 = s1;
@@ -826,7 +933,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             phase_stamp();
             epilogue();
             phase_stamp();
-            if (idx + gx >= t_end) break;
+            if (!has_nxt) break;
             next_tile();
             read_kstep_head(Ic<1>{});
             bar();  // every wave has re-read the new tile's first B fragments: steps 0-2 may now overwrite that B region
@@ -837,7 +944,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
             phase_stamp();
             epilogue();
             phase_stamp();
-            if (idx + gx >= t_end) break;
+            if (!has_nxt) break;
             next_tile();
             read_kstep_head(Ic<0>{});
             bar();
@@ -854,13 +961,13 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     }
 }
 
-template <int NT, int KIND, bool GELU, bool OUT_BF16>
+template <int NT, int KIND, bool GELU, bool OUT_BF16, bool SK = false>
 int launch_s4_kind(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl, int ldc, int n_sl,
                   const PrefillQkv& qa, hipStream_t s) {
     using P = S4<NT>;
     static bool raised = false;
     if (!raised) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, KIND, GELU, OUT_BF16>),
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, SK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS));
         raised = true;
     }
@@ -878,7 +985,7 @@ int launch_s4_kind(const bf16_t* A, const bf16_t* B, const float* bias, void* C,
         pa2 |= ((pl.pa_bits >> (4 * i)) & 3u) << (2 * i);
         pb2 |= ((pl.pb_bits >> (4 * i)) & 3u) << (2 * i);
     }
-    hipLaunchKernelGGL((gemm_s4_kernel<NT, KIND, GELU, OUT_BF16>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
+    hipLaunchKernelGGL((gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, SK>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
                        (unsigned)pl.lda | ((unsigned)pl.ldb << 16), (unsigned)ldc | ((unsigned)pl.kpp << 20) | ((unsigned)pl.npairs << 28),
                        pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10) | ((unsigned)n_sl << 20), qa);
     ZG_HIP(hipGetLastError());
@@ -906,6 +1013,16 @@ int launch_s4_nt(const bf16_t* A, const bf16_t* B, const float* bias, void* C, i
 // to the eight-wave kernel, whose arguments are not packed; api_ops.hip keeps ragged Linears beyond it on the GEMV path)
 bool gemm_s4_args_ok(const GemmPlanes& pl, int ldc) {
     return pl.lda > 0 && pl.ldb > 0 && pl.lda < 65536 && pl.ldb < 65536 && ldc < (1 << 20) && pl.kpp < 256 && pl.npairs <= 6;
+}
+
+int gemm_s4_fault(unsigned* out) {  // stream-K hand-over timed out since the last call?  (drains the device; clears the word)
+    ZG_HIP(hipDeviceSynchronize());
+    ZG_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s4_fault), sizeof(unsigned)));
+    if (*out) {
+        const unsigned zero = 0;
+        ZG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_s4_fault), &zero, sizeof zero));
+    }
+    return ZG_OK;
 }
 
 int gemm_s4_stamps(unsigned long long* out, size_t n_words) {
@@ -946,9 +1063,17 @@ int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, 
         case S4_PARTIAL:
             ZG_REQUIRE(bias == nullptr, ZG_ERR_ARG, "s4 prefill gemm: partial slabs carry no bias");
             return launch_s4_kind<3, S4_PARTIAL, false, false>(A, W, nullptr, C, M, N, pl, ldc, n_slices, none, s);
-        case S4_QKV:
+        case S4_QKV: {
             ZG_REQUIRE(qkv && N == 3 * qkv->E && n_slices == 1, ZG_ERR_ARG, "s4 prefill gemm: S4_QKV needs the cache description");
+            // 1.5 rounds of tiles (c_attn of eight 1023-token prompts: 384 tiles, 256 CUs): the last half round is split in K halves
+            // over ALL workgroups with a partial hand-over instead of running on half of the chip (gemm_s4_kernel, SK)
+            const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;
+            const int G = cus_env > 0 ? cus_env : 256, tiles = ((M + 255) / 256) * ((N + 191) / 192);
+            if (qkv->sk_ws != nullptr && qkv->sk_flags != nullptr && G % 16 == 0 && tiles > G && (tiles % G) * 2 == G && pl.kpp % 2 == 0 &&
+                pl.kpp >= 4 && (size_t)(G / 2) * 196608 <= qkv->sk_ws_bytes)
+                return launch_s4_kind<3, S4_QKV, false, false, true>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
             return launch_s4_kind<3, S4_QKV, false, false>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
+        }
         case S4_SPLIT3:
             ZG_REQUIRE(n_slices == 1, ZG_ERR_ARG, "s4 prefill gemm: S4_SPLIT3 is not sliced");
             return launch_s4_kind<3, S4_SPLIT3, true, true>(A, W, bias, C, M, N, pl, ldc, 1, none, s);

@@ -184,6 +184,7 @@ struct PrefillQkv;
 int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int nplanes, int kind, int n_slices,
                            const PrefillQkv* qkv, hipStream_t s);
 int gemm_s4_stamps(unsigned long long* out, size_t n_words);  // diagnostic (ZGPT2_GEMM_DBG bit 256)
+int gemm_s4_fault(unsigned* out);  // 1: a stream-K consumer of gemm_s4 gave up waiting for its producer since the last call (results wrong)
 int gemm_debug_stamps(unsigned long long* out, size_t n_words);  // of the kernel generation launched last
 unsigned long long gemm_mfma_launch_count();  // launches of the persistent MFMA GEMMs so far (tests assert the path taken)
 void gemm_note_launch();
@@ -207,6 +208,13 @@ struct PrefillQkv {
     void* k_cache;
     void* v_cache;
     size_t kv_lo;  // kv_mode 2: byte offset of the low-mantissa plane
+    // stream-K hand-over of the persistent GEMM (gemm_s4.hip, S4_QKV with 1.5 rounds of tiles): workspace for the producers'
+    // accumulators (196608 B per shared tile), one flag word per (shared tile, wave), the launch's epoch (flags of earlier
+    // launches are smaller); null = whole tiles only
+    void* sk_ws = nullptr;
+    size_t sk_ws_bytes = 0;
+    unsigned* sk_flags = nullptr;
+    unsigned sk_epoch = 0;
 };
 struct PrefillLn {
     const float* g;
