@@ -359,6 +359,11 @@ def main():
 
     bcast_ms = None
     bcast_note = None
+    # (RCCL prints a version banner through C stdio when a communicator is made; this program's stdout carries ONE JSON line, so
+    # file descriptor 1 points at stderr while the library's RCCL calls run, and C's buffers are flushed before it is restored)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     try:
         uid = (C.c_ubyte * 128)()
         if rank == 0:
@@ -379,6 +384,10 @@ def main():
         if world > 1:
             raise
         bcast_note = str(e)  # (a one-GPU box without librccl: nothing to broadcast to)
+    finally:
+        C.CDLL(None).fflush(None)
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     setup_s = time.perf_counter() - t0
 
     # ---- prompts: one token each, distinct per global prompt index

@@ -650,7 +650,9 @@ static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws
     const long tiles = (long)((M + 255) / 256) * ((N + 191) / 192);
     if (epi != PF_RESID) return tiles >= min_tiles ? 1 : 0;
     if (!have_ws) return 0;
-    for (int n_sl = 1; n_sl <= kpp / 2; ++n_sl) {
+    // (at most four slices: a one-prompt mlp c_proj cut into twelve — 16 tiles — ran 21.8 + 8.0 us of GEMM + reduce against 15.5 + 6.8
+    // on the 128-row kernel: profiles/round5_prefill_1x1023_kernel_stats.md of the first pass)
+    for (int n_sl = 1; n_sl <= kpp / 2 && (n_sl <= 4 || g_force_slices > 0); ++n_sl) {
         if (kpp % n_sl != 0 || (size_t)n_sl * M * N > ws_floats) continue;
         if (g_force_slices > 0 ? n_sl == g_force_slices : tiles * n_sl >= min_tiles) return n_sl;
     }
