@@ -200,11 +200,8 @@ def kernel_table(model, lib, cfg, ppg, wsz, kv_elem):
     ]
     table = []
     for which, name, n_launch, nbytes in classes:
-        os.environ["ZGPT2_TIME_CYCLE"] = "0"
         us, _ = model.time_kernel(which, 256)
-        os.environ["ZGPT2_TIME_CYCLE"] = "1"  # walk the layers: weights / KV from the memory side, as in the real step
-        us_cold, _ = model.time_kernel(which, 256)
-        os.environ["ZGPT2_TIME_CYCLE"] = "0"
+        us_cold, _ = model.time_kernel(which, 256, walk_layers=True)  # weights / KV from the memory side, as in the real step
         sym = C.create_string_buffer(160)
         _lib.check(lib.zg_debug_last_kernel(sym, 160))
         table.append({"class": name, "kernel_symbol": sym.value.decode(), "launches_per_token": n_launch, "avg_launch_us": round(us, 3),

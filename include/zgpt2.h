@@ -148,9 +148,13 @@ int zg_debug_prefill_linear(const uint16_t* A_planes, const uint16_t* W, const f
  * for all n_tokens positions of `batch` sequences at once).  qkv: fp32 [batch n_tokens][3 n_embed] rows (q | k | v columns);
  * out: bf16 planes [batch n_tokens][3 n_embed] = hi | mid | lo of the attention output; k_cache / v_cache: NULL (K and V are the
  * qkv columns) or head-major fp32 caches [batch][heads][ctx][64] holding the same rows; ws: fp32 workspace for the partials of
- * split key ranges (may be NULL: whole rows per workgroup).  Device pointers. */
+ * split key ranges (may be NULL: whole rows per workgroup); key_tiles: key tiles of 32 per workgroup, 0 = the library's choice.
+ * Device pointers. */
 int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t n_tokens, size_t n_embed, size_t n_heads,
-                          const float* k_cache, const float* v_cache, size_t ctx, float* ws, size_t ws_floats);
+                          const float* k_cache, const float* v_cache, size_t ctx, float* ws, size_t ws_floats, int key_tiles);
+/* Test hook: pin the route of every whole-prompt Linear of this process until called again with (0, 0) — force_kernel / slices
+ * as in zg_debug_prefill_linear.  tests/test_prefill_gpu.py runs small models through the persistent GEMM's epilogues with it. */
+int zg_debug_prefill_route(int force_kernel, int slices);
 /* Diagnostic: name of the kernel instantiation the last decode-kernel launcher of this thread picked (launches recorded
  * into a graph count; bench.py reports it as the symbol of the roofline kernel). */
 int zg_debug_last_kernel(char* out, size_t n);
@@ -276,8 +280,12 @@ int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t 
  * zg_gpt_profile_step: 0 embed ... 6 lm_head) `iters` times back to back from a hipGraph at
  * seq_len = context/2 and return the average device time per launch in microseconds (launch
  * boundary included) and the kernel's algorithmic weight bytes.  A warm-cache microbenchmark: the
- * in-situ numbers are zg_gpt_profile_step's. */
-int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes);
+ * in-situ numbers are zg_gpt_profile_step's.  Options ride in the upper bits of the class argument: ZG_TIME_WALK_LAYERS walks
+ * the layers (launch i takes layer i mod n_layer, so that no launch finds its weights in the L2s: the memory-side cost of the
+ * real step), ZG_TIME_AT(t) runs the chain at sequence length t. */
+#define ZG_TIME_WALK_LAYERS 0x100
+#define ZG_TIME_AT(t) ((int)((unsigned)(t) << 16))
+int zg_gpt_time_kernel(zg_gpt* g, int which_and_options, int iters, float* avg_us, size_t* algorithmic_bytes);
 
 /* Run `iters` consecutive decode steps starting at sequence length seq_len as EAGER launches with a
  * HIP event between every two kernels, and return the average device time in microseconds that

@@ -32,8 +32,6 @@ def planes_to_f64(bits, n):
     (1, 97, 12, 0, False, False), (3, 129, 2, 2, True, True), (1, 300, 4, 3, True, True), (2, 257, 3, 0, False, True),
     (1, 1023, 2, 0, True, False), (1, 1023, 2, 5, False, True)])
 def test_attn_prefill_matches_float64(zg, monkeypatch, B, P, H, tiles, cache, spike):
-    if tiles:
-        monkeypatch.setenv("ZGPT2_PF_ATTN_TILES", str(tiles))
     E, ctx = 64 * H, ((P + 63) // 64) * 64 + 64
     qkv = synth.fill_normal(21 + P, B * P * 3 * E, 0, 1.0).reshape(B * P, 3 * E)
     if spike:  # one key far above the rest for the queries behind it: the running maximum jumps by more than the deferral
@@ -53,7 +51,7 @@ def test_attn_prefill_matches_float64(zg, monkeypatch, B, P, H, tiles, cache, sp
         qkv_d[:, E:] = float("nan")  # the k / v columns of the rows must not be read
     torch.cuda.synchronize()  # (the fills above run on torch's stream, the library launches on its own)
     _lib.check(zg.zg_debug_attn_prefill(qkv_d.data_ptr(), out_d.data_ptr(), B, P, E, H, kc.data_ptr() if cache else None,
-                                        vc.data_ptr() if cache else None, ctx, ws.data_ptr(), ws.numel()))
+                                        vc.data_ptr() if cache else None, ctx, ws.data_ptr(), ws.numel(), tiles))
     torch.cuda.synchronize()
     got = planes_to_f64(out_d.cpu().numpy().view(np.uint16), E)
     ref = ref_attention(qkv, B, P, E, H)

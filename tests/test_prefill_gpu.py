@@ -18,6 +18,14 @@ from zig_gpt2_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def every_linear_on_s4(zg):
+    """Test hook of the C ABI: every whole-prompt Linear of the process takes the persistent four-wave GEMM, whatever its tile count."""
+    _lib.check(zg.zg_debug_prefill_route(1, 0))
+    yield
+    _lib.check(zg.zg_debug_prefill_route(0, 0))
+
+
 def make(cfg, seed, **kw):
     w = synth.make_weights(cfg, seed=seed, bf16=True)
     m = zgpt.GPT(cfg, **kw)
@@ -47,12 +55,11 @@ def test_prefill_logits_and_cache_match_oracle(zg, name, lengths):
 
 @pytest.mark.parametrize("name,batch,lengths,wgs", [("tiny", 1, [5, 33, 64], None), ("tiny", 3, [21, 64], 2), ("tiny3", 2, [48], 3),
                                                     ("nano-char", 4, [129, 256], None), ("xl-slice", 1, [95], 5), ("medium-slice", 2, [80], None)])
-def test_prefill_linears_on_the_persistent_four_wave_gemm(zg, monkeypatch, name, batch, lengths, wgs):
+def test_prefill_linears_on_the_persistent_four_wave_gemm(zg, monkeypatch, every_linear_on_s4, name, batch, lengths, wgs):
     """Large prompts run their Linears on gemm_s4 (three planes in one K loop; slab epilogue + reduce for the residual adds,
-    GELU + split, qkv + cache append).  ZGPT2_PF_S4_TILES=1 sends every shape there: small models, ragged tile edges (M far
+    GELU + split, qkv + cache append).  zg_debug_prefill_route(1, 0) sends every shape there: small models, ragged tile edges (M far
     below 256, N = 1600 = 8.33 tiles), several tiles per workgroup (ZGPT2_GEMM_WGS), K slices.  Same checks as the 128-row
     path: last-position logits and the decode step on top of the prefilled caches against the oracle."""
-    monkeypatch.setenv("ZGPT2_PF_S4_TILES", "1")
     if wgs:
         monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
     cfg = synth.CONFIGS[name]
@@ -71,11 +78,10 @@ def test_prefill_linears_on_the_persistent_four_wave_gemm(zg, monkeypatch, name,
     m.close()
 
 
-def test_prefill_c_attn_hands_half_tiles_over_between_workgroups(zg, monkeypatch):
+def test_prefill_c_attn_hands_half_tiles_over_between_workgroups(zg, monkeypatch, every_linear_on_s4):
     """1.5 rounds of c_attn tiles (eight 1023-token prompts at 124M: 384 tiles on 256 CUs) run as whole tiles plus K halves of the
     last half round on ALL workgroups, the producer's accumulators handed to its consumer through memory (gemm_s4.hip, SK).
     Small stand-in with the same geometry: nano-char, 4 x 256 tokens = 4 x 6 tiles on 16 workgroups (16 whole + 8 shared)."""
-    monkeypatch.setenv("ZGPT2_PF_S4_TILES", "1")
     monkeypatch.setenv("ZGPT2_GEMM_WGS", "16")
     cfg = synth.CONFIGS["nano-char"]
     m, w = make(cfg, 77, batch=4)

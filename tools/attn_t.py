@@ -8,7 +8,6 @@ for name, B in (("124M", 1), ("124M", 8), ("xl", 1)):
     cfg = synth.CONFIGS[name]
     m = gpt.GPT(cfg, batch=B)
     for T in (64, 256, 257, 512, 768, 1024):
-        os.environ["ZGPT2_TIME_T"] = str(T)
-        us, _ = m.time_kernel(2, 256)
+        us, _ = m.time_kernel(2, 256, at=T)
         print(name, B, "T", T, "attention us", round(us, 2), flush=True)
     m.close()

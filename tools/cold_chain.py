@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch chain cost of each decode kernel class with the SAME layer's weights every launch (they stay in the
-XCDs' L2s: what bench.py's kernel_classes reports) against walking the layers (ZGPT2_TIME_CYCLE=1: weights from the
+XCDs' L2s: what bench.py's kernel_classes reports) against walking the layers (time_kernel(walk_layers=True): weights from the
 memory side, as in the real step).  Random-init weights are not needed: the timing does not depend on values.
     python tools/cold_chain.py [124M|xl ...]"""
 import os, sys
@@ -17,8 +17,7 @@ for spec in (sys.argv[1:] or ["124M", "124M:8", "xl"]):
     for w in range(1, 6):
         row = {"model": name, "batch": int(b or 1), "class": w}
         for cyc in (0, 1, 0, 1):
-            os.environ["ZGPT2_TIME_CYCLE"] = str(cyc)
-            us, _ = m.time_kernel(w, 1024)
+            us, _ = m.time_kernel(w, 1024, walk_layers=bool(cyc))
             row.setdefault("cycle" if cyc else "same_layer", []).append(round(us, 3))
         print(json.dumps(row), flush=True)
     m.close()

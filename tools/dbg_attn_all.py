@@ -8,8 +8,6 @@ cases = [(1, 1, 2, 0, False, False), (2, 31, 2, 0, False, False), (1, 32, 3, 0, 
     (1, 97, 12, 0, False, False), (3, 129, 2, 2, True, True), (1, 300, 4, 3, True, True), (2, 257, 3, 0, False, True),
     (1, 1023, 2, 0, True, False), (1, 1023, 2, 5, False, True)]
 def run(B, P, H, tiles, cache, spike):
-    if tiles: os.environ["ZGPT2_PF_ATTN_TILES"] = str(tiles)
-    else: os.environ.pop("ZGPT2_PF_ATTN_TILES", None)
     E, ctx = 64 * H, ((P + 63) // 64) * 64 + 64
     qkv = synth.fill_normal(21 + P, B * P * 3 * E, 0, 1.0).reshape(B * P, 3 * E)
     if spike:
@@ -29,7 +27,7 @@ def run(B, P, H, tiles, cache, spike):
         qkv_d[:, E:] = float("nan")
     torch.cuda.synchronize()
     _lib.check(zg.zg_debug_attn_prefill(qkv_d.data_ptr(), out_d.data_ptr(), B, P, E, H, kc.data_ptr() if cache else None,
-                                        vc.data_ptr() if cache else None, ctx, ws.data_ptr(), ws.numel()))
+                                        vc.data_ptr() if cache else None, ctx, ws.data_ptr(), ws.numel(), tiles))
     torch.cuda.synchronize()
     got = T.planes_to_f64(out_d.cpu().numpy().view(np.uint16), E)
     ref = T.ref_attention(qkv, B, P, E, H)

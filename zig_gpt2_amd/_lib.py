@@ -46,7 +46,8 @@ SIGNATURES = {
     "zg_debug_gemm_launches": (C.c_ulonglong, []),
     "zg_debug_gemm_stamps": (C.c_int, [vp, sz]),
     "zg_debug_last_kernel": (C.c_int, [C.c_char_p, sz]),
-    "zg_debug_attn_prefill": (C.c_int, [vp, vp, sz, sz, sz, sz, vp, vp, sz, vp, sz]),
+    "zg_debug_attn_prefill": (C.c_int, [vp, vp, sz, sz, sz, sz, vp, vp, sz, vp, sz, C.c_int]),
+    "zg_debug_prefill_route": (C.c_int, [C.c_int, C.c_int]),
     "zg_debug_prefill_linear": (C.c_int, [vp, vp, vp, vp, sz, sz, sz, C.c_int, C.c_int, C.c_int, vp, sz]),
     "zg_linear_forward": (C.c_int, [sz, sz, vp, vp, vp, sz, vp, sz]),
     "zg_embedding_forward": (C.c_int, [sz, vp, sz, vp, sz, vp, sz]),
@@ -121,11 +122,10 @@ def load():
     # requested by torch as "libamdhip64.so").  If this library pulled in /opt/rocm's copy first, a
     # later `import torch` would load a second runtime that finds no GPU.  Importing torch first makes
     # the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already loaded.
-    if os.environ.get("ZGPT2_NO_TORCH_PRELOAD") != "1":
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(SO_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -661,7 +661,7 @@ int pf_start(zg_gpt* g, size_t last_T, hipStream_t s) {
         if (idle_exit) {  // a strike, not a verdict: one slow host moment inside a generate loop produces the same exit
             g->pf_stalled = true;
             ++g->pf_strikes;
-            g->pf_sit_out = env_int("ZGPT2_PF_REARM", 8);  // generate calls without it before the next try
+            g->pf_sit_out = 8;  // generate calls without it before the next try
         }
     }
     if (g->pf_stalled) {
@@ -1321,19 +1321,19 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
     return check_fault(g);  // (every event above was synchronised: timings of a faulted step are not reported)
 }
 
-int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* algorithmic_bytes) {
+int zg_gpt_time_kernel(zg_gpt* g, int which_and_options, int iters, float* avg_us, size_t* algorithmic_bytes) {
     ZG_TRY(require_init());
-    ZG_REQUIRE(g && avg_us && iters > 0 && which >= 0 && which <= 6, ZG_ERR_ARG, "time_kernel: bad argument");
+    const int which = which_and_options & 0xff;
+    const bool cycle = (which_and_options & ZG_TIME_WALK_LAYERS) != 0;  // walk the layers, so that no launch finds its weights in the L2s
+    const size_t t_opt = (size_t)((unsigned)which_and_options >> 16);    // another position for the attention kernel (0: mid-context)
+    ZG_REQUIRE(g && avg_us && iters > 0 && which_and_options >= 0 && which <= 6, ZG_ERR_ARG, "time_kernel: bad argument");
     hipStream_t s = ctx().stream;
     ZG_REQUIRE(s != nullptr, ZG_ERR_UNSUPPORTED, "time_kernel needs a capturable stream");
     const size_t E = g->cfg.n_embed, wb = g->wbytes;
     const size_t bytes_tab[7] = {0, 3 * E * E * wb, 0, E * E * wb, 4 * E * E * wb, 4 * E * E * wb, g->cfg.vocab_size * E * wb};
     // control block: a mid-context position so that the attention kernel has work
     size_t T = g->cfg.context_size / 2 > 0 ? g->cfg.context_size / 2 : 1;
-    if (const char* e = getenv("ZGPT2_TIME_T")) {  // measurement: another position for the attention kernel
-        const long v = atol(e);
-        if (v >= 1 && (size_t)v <= g->cfg.context_size) T = (size_t)v;
-    }
+    if (t_opt >= 1 && t_opt <= g->cfg.context_size) T = t_opt;
     ZG_HIP(hipStreamSynchronize(s));
     ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(note_steps(g, (size_t)iters + 8, s));  // (one epoch per replay of the chain)
@@ -1347,8 +1347,6 @@ int zg_gpt_time_kernel(zg_gpt* g, int which, int iters, float* avg_us, size_t* a
     hipGraphExec_t exec = nullptr;
     ZG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int st = ZG_OK;
-    // ZGPT2_TIME_CYCLE=1 (measurement): walk the layers, so that no launch finds its weights in the L2s
-    const bool cycle = getenv("ZGPT2_TIME_CYCLE") && atoi(getenv("ZGPT2_TIME_CYCLE")) != 0;
     // tagged hand-overs: a new epoch per replay and a launch id per chain position, so that every merging split / slice
     // waits for ITS writers as in a real step (one more tiny launch per 64)
     if (g->tags_on && which != 0) st = launch_epoch_bump(g->epoch, s);

@@ -441,14 +441,22 @@ int zg_debug_prefill_linear(const uint16_t* A, const uint16_t* W, const float* b
 }
 
 int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t n_tokens, size_t n_embed, size_t n_heads, const float* k_cache,
-                          const float* v_cache, size_t ctx_len, float* ws, size_t ws_floats) {
+                          const float* v_cache, size_t ctx_len, float* ws, size_t ws_floats, int key_tiles) {
     ZG_TRY(require_init());
     ZG_REQUIRE(qkv && out && is_device_ptr(qkv) && is_device_ptr(out) && (!k_cache || (v_cache && is_device_ptr(k_cache) && is_device_ptr(v_cache))) &&
                    (!ws || is_device_ptr(ws)),
                ZG_ERR_ARG, "debug_attn_prefill: device pointers");
-    ZG_REQUIRE(batch >= 1 && n_tokens >= 1 && batch * n_tokens < (1u << 24) && n_embed < (1u << 16) && (!k_cache || ctx_len >= n_tokens), ZG_ERR_ARG,
-               "debug_attn_prefill: arguments");
-    return launch_attn_prefill(qkv, out, (int)batch, (int)n_tokens, (int)n_embed, (int)n_heads, ws, ws_floats, k_cache, v_cache, (int)ctx_len, ctx().stream);
+    ZG_REQUIRE(batch >= 1 && n_tokens >= 1 && batch * n_tokens < (1u << 24) && n_embed < (1u << 16) && (!k_cache || ctx_len >= n_tokens) &&
+                   key_tiles >= 0 && key_tiles <= 255,
+               ZG_ERR_ARG, "debug_attn_prefill: arguments");
+    return launch_attn_prefill(qkv, out, (int)batch, (int)n_tokens, (int)n_embed, (int)n_heads, ws, ws_floats, k_cache, v_cache, (int)ctx_len, ctx().stream,
+                               key_tiles);
+}
+
+int zg_debug_prefill_route(int force_kernel, int slices) {
+    ZG_REQUIRE(force_kernel >= 0 && force_kernel <= 2 && slices >= 0, ZG_ERR_ARG, "debug_prefill_route: arguments");
+    prefill_force_route(force_kernel, slices);
+    return ZG_OK;
 }
 
 unsigned long long zg_debug_gemm_launches(void) { return gemm_mfma_launch_count(); }

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const float* __
 // k_cache / v_cache != null: K and V come from the head-major fp32 caches [b][h][ctx][64] (positions 0 .. P - 1 just appended
 // by the c_attn epilogue) instead of the k / v columns of qkv.
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, const float* k_cache,
-                        const float* v_cache, int ctx, hipStream_t s) {
+                        const float* v_cache, int ctx, hipStream_t s, int force_tiles) {
     static bool raised = false;
     if (!raised) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
@@ -400,8 +400,7 @@ int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int 
     int nts = 32 * ((nqb + 31) / 32);
     {
         const long groups = (long)B * H * ng;
-        const int env = getenv("ZGPT2_PF_ATTN_TILES") ? atoi(getenv("ZGPT2_PF_ATTN_TILES")) : 0;
-        if (env > 0) nts = env;
+        if (force_tiles > 0) nts = force_tiles;
         else
             for (int cand = nts; cand >= 4; cand /= 2) {
                 long wgs = 0;

@@ -636,13 +636,13 @@ int launch_ln_split(const float* x, int M, int E, const float* g, const float* b
 // N = n_embed Linears (residual adds) get there by slicing K over the tile list, their partial slabs summed by the reduce
 // kernels above in fixed order (which also apply bias, residual and the LayerNorm + split that follows).  Returns the slice
 // count, 0 = the 128-row kernels of this file take the launch.
-static int g_force_kernel = 0, g_force_slices = 0;  // zg_debug_prefill_linear: 1 = gemm_s4, 2 = the 128-row kernels; K slices
+static int g_force_kernel = 0, g_force_slices = 0;  // zg_debug_prefill_route / _linear: 1 = gemm_s4, 2 = the 128-row kernels; K slices
 void prefill_force_route(int kernel, int slices) {
     g_force_kernel = kernel;
     g_force_slices = slices;
 }
 static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws) {
-    int min_tiles = getenv("ZGPT2_PF_S4_TILES") ? atoi(getenv("ZGPT2_PF_S4_TILES")) : 192;  // tiles of 256 x 192 (x K slices) from which the persistent kernel takes the launch: three quarters of the CUs
+    int min_tiles = 192;  // tiles of 256 x 192 (x K slices) from which the persistent kernel takes the launch: three quarters of the CUs
     if (g_force_kernel == 1) min_tiles = 1;
     if (g_force_kernel == 2) return 0;
     const int kpp = K / 64;

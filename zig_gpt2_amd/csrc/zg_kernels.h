@@ -227,11 +227,11 @@ int launch_prefill_gemm(const bf16_t* A, const bf16_t* W, const float* bias, voi
                         int nsplit = kSplit);  // nsplit = 2: multiply the hi + mid planes only (2/3 of the matrix work);
                                                // kWeightPlanes: W is the plane-major three-term split [3][N][K] of an fp32 matrix
 constexpr int kWeightPlanes = 33;
-void prefill_force_route(int kernel, int slices);  // zg_debug_prefill_linear: pin the GEMM family (1 gemm_s4, 2 the 128-row kernels) and the K slices
+void prefill_force_route(int kernel, int slices);  // zg_debug_prefill_route / _linear: pin the GEMM family (1 gemm_s4, 2 the 128-row kernels) and the K slices
 // out[M][kSplit E] = split(causal attention of the q / k / v columns of qkv[M][3E]), M = B P rows ordered (b, t)
 // (attn_prefill.hip: bf16 matrix cores on exact plane splits; ws = fp32 workspace for the partials of split key ranges)
 int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int H, float* ws, size_t ws_floats, const float* k_cache_or_null,
-                        const float* v_cache_or_null, int ctx, hipStream_t s);
+                        const float* v_cache_or_null, int ctx, hipStream_t s, int force_tiles = 0);  // force_tiles: key tiles per workgroup (tests)
 
 // GPT.sample tail: in-place softmax(logits / temp) per sequence + inverse-CDF draw with uniform u[b].
 int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s);

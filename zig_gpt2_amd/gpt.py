@@ -152,9 +152,11 @@ class GPT:
         return {"on": bool(out[0]), "stalled": int(out[0]) == 2, "workgroups": out[1:9].tolist(), "exit": out[9:17].tolist(), "jobs": out[17:25].tolist(),
                 "xcd_of_block0": [int(v) & 15 for v in out[25:] if v & 0x100]}
 
-    def time_kernel(self, which, iters):
+    def time_kernel(self, which, iters, walk_layers=False, at=0):
+        """walk_layers: launch i of the chain takes layer i mod n_layer (weights / KV from the memory side, as in the real step);
+        at: the sequence length the chain runs at (0: mid-context).  ZG_TIME_WALK_LAYERS / ZG_TIME_AT of include/zgpt2.h."""
         us, nbytes = C.c_float(), C.c_size_t()
-        check(self._L.zg_gpt_time_kernel(self.h, which, iters, C.byref(us), C.byref(nbytes)))
+        check(self._L.zg_gpt_time_kernel(self.h, which | (0x100 if walk_layers else 0) | (int(at) << 16), iters, C.byref(us), C.byref(nbytes)))
         return us.value, nbytes.value
 
 
