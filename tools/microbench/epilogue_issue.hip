@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256 * W, 1) void k(const float* __restrict__ src, u
         st_r[c] = st_base + (unsigned)row * kStRow + (unsigned)col16 * 16u;
     }
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7FFFFFFF, 0x00020000);
-    // tile of this workgroup: rows 256 b .. +255 of a [65536][192] bf16 matrix; wave w of W = 1 takes rows 64 w (2 x 32 ... as 4 m-tiles of
-    // 32 over its 128 x 96 half: the geometry only has to give whole-line stores, not the GEMM's exact map)
+    // tile of this workgroup: rows 256 b .. +255 of a [65536][192] bf16 matrix; waves 2 x 2 over 128 x 96 quarters (W = 1) or
+    // 4 x 2 over 64 x 96 eighths (W = 2), m-tiles of 32 rows each
     const unsigned tile_off = (unsigned)blockIdx.x * 256u * 384u;
     unsigned long long total = 0;
     for (int it = 0; it < iters; ++it) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256 * W, 1) void k(const float* __restrict__ src, u
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     const int piece = c * 64 + lane, row = piece / 12, col16 = piece % 12;
-                    const unsigned off = tile_off + (unsigned)((wave * MT + i) * 32 + row) * 384u + (unsigned)col16 * 16u;
+                    const unsigned off = tile_off + (unsigned)(((wave >> 1) * MT + i) * 32 + row) * 384u + (unsigned)(wave & 1) * 192u + (unsigned)col16 * 16u;
                     __builtin_amdgcn_raw_buffer_store_b128(o[c], rc, off, 0, 0);
                 }
             }
