@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
     const int nqb = (P + 31) >> 5;
     const int kt0 = s * nts, kt1 = min((s + 1) * nts, group_tiles(g, nqb));
     if (kt0 >= kt1) return;
+#ifdef ZG_STAMPS  // diagnostic build: every workgroup's start / end (s_memrealtime, 100 MHz) and where it ran -> part[] (unsplit launches only)
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int n_t = kt1 - kt0;
     const int qb = 4 * g + wave, tq = qb * 32 + l31;
     const size_t row0 = (size_t)b * P;
@@ -327,6 +330,16 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
             body(std::integral_constant<int, 0>{}, F{}, i);
         }
     }
+#ifdef ZG_STAMPS
+    if (tid == 0 && max_s == 1) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(part) + 4 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        st[0] = stamp0;
+        st[1] = __builtin_amdgcn_s_memrealtime();
+        st[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |         // HW_REG_HW_ID
+                ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+        st[3] = (unsigned long long)n_t;
+    }
+#endif
     if (qb >= nqb || tq >= P) return;
 
     // O^T: the lane holds d = (r & 3) + 8 (r >> 2) + 4 hl (+ 32 in o1) of its query
