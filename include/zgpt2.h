@@ -153,7 +153,9 @@ int zg_debug_prefill_linear(const uint16_t* A_planes, const uint16_t* W, const f
 int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t n_tokens, size_t n_embed, size_t n_heads,
                           const float* k_cache, const float* v_cache, size_t ctx, float* ws, size_t ws_floats, int key_tiles);
 /* Test hook: pin the route of every whole-prompt Linear of this process until called again with (0, 0) — force_kernel / slices
- * as in zg_debug_prefill_linear.  tests/test_prefill_gpu.py runs small models through the persistent GEMM's epilogues with it. */
+ * as in zg_debug_prefill_linear; force_kernel >= 16: the library's rule with that many 256 x 192 tiles (x K slices) as the
+ * threshold from which the persistent GEMM takes a Linear (default 192; tools/experiments/pf_route_ab.py).
+ * tests/test_prefill_gpu.py runs small models through the persistent GEMM's epilogues with it. */
 int zg_debug_prefill_route(int force_kernel, int slices);
 /* Diagnostic: name of the kernel instantiation the last decode-kernel launcher of this thread picked (launches recorded
  * into a graph count; bench.py reports it as the symbol of the roofline kernel). */

@@ -237,6 +237,30 @@ def test_prefill_with_fp32_weights(zg, name, lengths):
     m.close()
 
 
+@pytest.mark.parametrize("name,batch,n,wgs", [("tiny3", 2, 48, None), ("nano-char", 4, 256, 16), ("xl-slice", 1, 95, 5), ("medium-slice", 2, 80, None)])
+def test_prefill_fp32_weights_on_the_persistent_four_wave_gemm(zg, monkeypatch, every_linear_on_s4, name, batch, n, wgs):
+    """fp32 weights on gemm_s4: the six plane products a_i w_j (i + j <= 2) of the activation planes and the weight's three plane
+    matrices are the plane pairs of ONE K loop (6 K / 64 K-steps per tile) instead of three passes over partial slabs.  Same
+    checks as with bf16 weights, against the fp32 oracle; nano-char 4 x 256 on 16 workgroups also hands half tiles over."""
+    if wgs:
+        monkeypatch.setenv("ZGPT2_GEMM_WGS", str(wgs))
+    cfg = synth.CONFIGS[name]
+    w = synth.make_weights(cfg, seed=78, bf16=False)
+    m = zgpt.GPT(cfg, batch=batch, weights_f32=True)
+    m.load_weights(w)
+    toks = np.stack([synth.rand_tokens(780 + 7 * b + n, min(n + 1, cfg.context_size), cfg.vocab_size) for b in range(batch)])
+    before = zg.zg_debug_gemm_launches()
+    lg = m.prefill(toks[:, :n])
+    assert zg.zg_debug_gemm_launches() - before >= 4 * cfg.n_layer, "the whole-prompt Linears did not run on gemm_s4"
+    nxt = m.forward(n + 1, toks[:, n]) if n < cfg.context_size else None
+    for b in range(batch):
+        lg_ref = oracle.GPT(cfg, w).forced_logits(toks[b], n - 1)
+        assert_model_close(lg_ref[0], lg[b], f"{name} fp32-weight s4 prefill row {b}")
+        if nxt is not None:
+            assert_model_close(lg_ref[1], nxt[b], f"{name} decode after fp32-weight s4 prefill row {b}")
+    m.close()
+
+
 def test_prefill_two_plane_mode_is_inside_the_parity_bound(zg):
     """ZG_GPT_PREFILL_2PLANE: hi + mid planes of the activations only.  north_star's bound is 1e-3 relative; the
     two-plane error is ~2e-5 of the logit scale, so it is stated against the logit scale (not against the

@@ -454,7 +454,7 @@ int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t 
 }
 
 int zg_debug_prefill_route(int force_kernel, int slices) {
-    ZG_REQUIRE(force_kernel >= 0 && force_kernel <= 2 && slices >= 0, ZG_ERR_ARG, "debug_prefill_route: arguments");
+    ZG_REQUIRE(force_kernel >= 0 && (force_kernel <= 2 || force_kernel >= 16) && slices >= 0, ZG_ERR_ARG, "debug_prefill_route: arguments");
     prefill_force_route(force_kernel, slices);
     return ZG_OK;
 }

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     // All 14 dwords of the arguments are preloaded into SGPRs at wave launch (zg_common.h ZG_PIN): the first version passed the
     // plane description and the tile counts behind them and began with a scalar round trip to the kernarg segment — cold for
     // every launch — before its first DMA.  p0 = lda | ldb << 16; p1 = ldc | K-steps per plane << 20 | plane pairs << 28;
-    // p2 = A plane of pair i in bits [2i, 2i + 2) | B planes << 12 | band width << 24; p3 = workgroups | dbg << 10 | K slices << 20.
+    // p2 = A plane of pair i in bits [2i, 2i + 2) | B planes << 12 | band width << 24; p3 = workgroups | dbg << 10 | K slices << 20 |
+    // B planes are matrices << 31.
     // (qa — the cache description of S4_QKV — lies behind the preloaded dwords: its fields are fetched under the first DMA)
     using P = S4<NT>;
     GemmPlanes pl;
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     pl.pb_bits = (p2 >> 12) & 0xfffu;
     const int gw = (int)(p2 >> 24);
     const int dbg = (int)((p3 >> 10) & 0x3ffu);
-    const int n_sl = KIND == S4_PARTIAL ? (int)(p3 >> 20) : 1;  // K slices: slice s of a tile walks K-steps [s kps, (s + 1) kps) of every plane
+    const int n_sl = KIND == S4_PARTIAL ? (int)((p3 >> 20) & 0xffu) : 1;  // K slices: slice s of a tile walks K-steps [s kps, (s + 1) kps) of every plane
+    const bool b_major = (p3 >> 31) != 0u;  // B = three plane matrices [3][N][ldb] (fp32 weights of the model) instead of planes side by side in a row
     const int tiles_m = (M + 255) >> 8, tiles_n = (N + P::BN - 1) / P::BN;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     const __amdgpu_buffer_rsrc_t ra =
         __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * pl.lda * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb =
-        __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * pl.ldb * 2), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * pl.ldb * 2) * (b_major ? 3u : 1u), 0x00020000);
     // The tile's bias row travels through LDS (wave 0 fetches it by LDS-DMA at the start of the tile; columns past N and a
     // null bias read as zero): the epilogue must not issue a global load — the compiler would wait for it with vmcnt(0),
     // i.e. drain the stores and the next tile's DMA — and 48 registers of bias held across the epilogue make the register
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
     locate(idx, tm, tn, sl);
     const unsigned strideA = 256u * lda2, strideB = (unsigned)P::BN * ldb2, strideK = (unsigned)kps_full * 128u;
     const unsigned halfK = (unsigned)(kpp >> 1) * 128u;  // SK: where the consumer's half of a plane begins
+    const unsigned plane_b = b_major ? (unsigned)N * ldb2 : (unsigned)kpp * 128u;  // from one B plane to the next
     unsigned curA = (unsigned)tm * strideA + (unsigned)sl * strideK + (unsigned)half_cur * halfK;
     unsigned curB = (unsigned)tn * strideB + (unsigned)sl * strideK + (unsigned)half_cur * halfK;
     int m0 = tm * 256, n0 = tn * P::BN;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
         const unsigned pa = (pl.pa_bits >> (2 * pi)) & 3u, pb = (pl.pb_bits >> (2 * pi)) & 3u;
         Ahead s;
         s.kbA = (pa * (unsigned)kpp + (unsigned)kk) * 128u;
-        s.kbB = (pb * (unsigned)kpp + (unsigned)kk) * 128u;
+        s.kbB = pb * plane_b + (unsigned)kk * 128u;
         s.baseA = in_cur ? curA : nxtA;
         s.baseB = in_cur ? curB : nxtB;
         return s;
@@ -987,7 +990,7 @@ int launch_s4_kind(const bf16_t* A, const bf16_t* B, const float* bias, void* C,
     }
     hipLaunchKernelGGL((gemm_s4_kernel<NT, KIND, GELU, OUT_BF16, SK>), dim3(grid), dim3(256), P::LDS, s, A, B, bias, C, M, N,
                        (unsigned)pl.lda | ((unsigned)pl.ldb << 16), (unsigned)ldc | ((unsigned)pl.kpp << 20) | ((unsigned)pl.npairs << 28),
-                       pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10) | ((unsigned)n_sl << 20), qa);
+                       pa2 | (pb2 << 12) | ((unsigned)gw << 24), (unsigned)grid | (dbg << 10) | ((unsigned)n_sl << 20) | (pl.b_plane_major ? 0x80000000u : 0u), qa);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -1040,18 +1043,29 @@ int launch_gemm_s4(const bf16_t* A, const bf16_t* B, const float* bias, void* C,
 
 // The whole-prompt Linears on the same kernel (prefill.hip decides when): A = the activation planes [M][nplanes K] (hi | mid | lo),
 // W = the bf16 weight [N][K]; the planes are plane pairs of ONE K loop, smallest first — a tile's accumulators see 3 K / 64
-// K-steps between two epilogues.  kind: S4_PARTIAL (C = fp32 slabs [n_slices][M][N], bias must be null), S4_QKV (C = qkv [M][N]
-// fp32 + cache append), S4_SPLIT3 (C = bf16 planes [M][3 N] of gelu(...)).
+// K-steps between two epilogues.  nplanes == kWeightPlanes: W = the three plane matrices [3][N][K] of an fp32 weight, and the six
+// plane products a_i w_j, i + j <= 2, are the pairs (6 K / 64 K-steps per tile; what is dropped is below 2^-24 of the leading
+// term).  kind: S4_PARTIAL (C = fp32 slabs [n_slices][M][N], bias must be null), S4_QKV (C = qkv [M][N] fp32 + cache append),
+// S4_SPLIT3 (C = bf16 planes [M][3 N] of gelu(...)).
 int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, void* C, int M, int N, int K, int nplanes, int kind, int n_slices,
                            const PrefillQkv* qkv, hipStream_t s) {
-    ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0 && K >= 128 && (nplanes == 2 || nplanes == 3), ZG_ERR_UNSUPPORTED, "s4 prefill gemm: M=%d N=%d K=%d planes=%d", M, N, K, nplanes);
+    ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0 && K >= 128 && (nplanes == 2 || nplanes == 3 || nplanes == kWeightPlanes), ZG_ERR_UNSUPPORTED,
+               "s4 prefill gemm: M=%d N=%d K=%d planes=%d", M, N, K, nplanes);
     GemmPlanes pl{};
     pl.lda = kSplit * K;  // the plane buffer always holds three planes per row; nplanes = 2 multiplies hi + mid only
     pl.ldb = K;
     pl.kpp = K / 64;
-    pl.npairs = nplanes;
-    pl.pa_bits = nplanes == 3 ? 0x012u : 0x01u;  // pair 0 = the smallest plane
-    pl.pb_bits = 0;
+    if (nplanes == kWeightPlanes) {  // (a, w) = (lo, hi) (mid, mid) (hi, lo) (mid, hi) (hi, mid) (hi, hi): smallest terms first
+        pl.npairs = 6;
+        pl.pa_bits = 0x001012u;
+        pl.pb_bits = 0x010210u;
+        pl.b_plane_major = true;
+        ZG_REQUIRE((size_t)N * K * 2 * 3 < ((size_t)1 << 31), ZG_ERR_SHAPE, "s4 prefill gemm: weight planes of %d x %d beyond a 32-bit buffer descriptor", N, K);
+    } else {
+        pl.npairs = nplanes;
+        pl.pa_bits = nplanes == 3 ? 0x012u : 0x01u;  // pair 0 = the smallest plane
+        pl.pb_bits = 0;
+    }
     const int ldc = kind == S4_SPLIT3 ? kSplit * N : N;
     const size_t out_bytes = (size_t)(kind == S4_PARTIAL ? n_slices : 1) * M * ldc * (kind == S4_SPLIT3 ? 2 : 4);
     ZG_REQUIRE(out_bytes < ((size_t)1 << 32) && (size_t)M * pl.lda * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 31), ZG_ERR_SHAPE,

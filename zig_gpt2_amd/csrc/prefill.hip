@@ -644,6 +644,7 @@ void prefill_force_route(int kernel, int slices) {
 static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws) {
     int min_tiles = 192;  // tiles of 256 x 192 (x K slices) from which the persistent kernel takes the launch: three quarters of the CUs
     if (g_force_kernel == 1) min_tiles = 1;
+    if (g_force_kernel >= 16) min_tiles = g_force_kernel;  // (measurement: another threshold)
     if (g_force_kernel == 2) return 0;
     const int kpp = K / 64;
     if (K % 64 != 0 || kpp < 2 || kSplit * K >= 65536) return 0;
@@ -662,7 +663,7 @@ static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
                         float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv, int nsplit) {
     ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
-    if (nsplit != kWeightPlanes) {
+    {
         const int n_sl = s4_route(M, N, K, epi, ws_floats, ws != nullptr);
         if (n_sl > 0 && epi == PF_RESID && ldc == N) {
             ZG_TRY(launch_gemm_s4_prefill(A, B, nullptr, ws, M, N, K, nsplit, S4_PARTIAL, n_sl, nullptr, s));

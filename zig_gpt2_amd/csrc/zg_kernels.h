@@ -172,6 +172,7 @@ struct GemmPlanes {
     int kpp;       // K-steps (of 64) per plane
     int npairs;
     unsigned pa_bits, pb_bits;
+    bool b_plane_major;  // B's planes are whole [N][ldb] matrices one behind the other (the model's fp32-weight planes), not column blocks of a row
 };
 int launch_gemm_planes(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, const GemmPlanes& pl,
                        int ldc, bool gelu, bool out_bf16, hipStream_t s);
