@@ -408,8 +408,10 @@ int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int 
     }
     ZG_REQUIRE(E == H * 64, ZG_ERR_UNSUPPORTED, "attention prefill: head_dim must be 64 (n_embed %d, %d heads)", E, H);
     const int nqb = (P + 31) / 32, ng = (nqb + 3) / 4;
-    // key tiles per workgroup: whole rows once the launch fills the chip about twice (2 workgroups fit a CU), else ranges of
-    // >= 4 tiles chosen so that it does — as long as the partials fit the workspace
+    // key tiles per workgroup: whole rows once there is a group per CU (measured at 12 heads x 1023 tokens, tools/bench_attn_prefill.py:
+    // 4 / 5 sequences = 384 / 480 groups run 57 / 66 us whole against 62 / 75 us cut in two with the merge kernel behind; 3 sequences
+    // are even, 2 are faster cut), else ranges of >= 4 tiles chosen so that the launch fills the chip about twice (2 workgroups fit a
+    // CU) — as long as the partials fit the workspace
     int nts = 32 * ((nqb + 31) / 32);
     {
         const long groups = (long)B * H * ng;
@@ -419,7 +421,7 @@ int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int 
                 long wgs = 0;
                 for (int g = 0; g < ng; ++g) wgs += group_splits(g, nqb, cand);
                 nts = cand;
-                if (wgs * B * H >= 512 || groups >= 512) break;
+                if (wgs * B * H >= 512 || groups >= 256) break;
             }
         if (nts > 255) nts = 255;
     }
