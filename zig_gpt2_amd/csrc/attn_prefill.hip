@@ -185,24 +185,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
     const int koff = l31 * 128, kswz = (l31 >> 1) & 7;
     const int voff = ((lane >> 4) & 1) * kVBlock + (4 * hl + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     constexpr int PK[6] = {2, 0, 1, 1, 0, 0}, PQ[6] = {0, 2, 1, 0, 1, 0};  // the six plane pairs (k or v plane, q or p plane), smallest first
-    // S^T = K Q^T of the tile in K slot `slot`, as TWO accumulator chains taking the plane pairs in turn: an MFMA that follows
-    // another one on the same accumulator must follow it directly (anything issued between them costs the accumulate forwarding, ~43
-    // cycles), whereas between MFMAs on different accumulators ~5 other instructions are free — which is where this wave's vector
-    // work goes (MI355X_MICROARCH.md, per-instruction constants).  The caller adds the two halves.
-    auto s_tile = [&](int slot, f32x16& sa, f32x16& sb) {
+    // S^T = K Q^T of the tile in K slot `slot`: ONE accumulator chain, the 24 MFMAs back to back (an MFMA that follows another one on
+    // the same accumulator must follow it directly: anything issued between them costs the accumulate forwarding, ~43 cycles —
+    // MI355X_MICROARCH.md, per-instruction constants).  Two chains taking the plane pairs in turn — which let this wave's own vector
+    // work issue between MFMAs — cost 16 additions per tile to join and ran 1 % slower (89.6 against 90.6 us at 8 x 1023, same box):
+    // the SIMD's other wave fills the matrix pipe's shadow anyway (tools/microbench/pingpong_probe.hip).
+    auto s_tile = [&](int slot, f32x16& sa) __attribute__((always_inline)) {
         const char* kp = kring + slot * 3 * kKPlane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) sa[r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 kf[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(kp + p * kKPlane + koff + (((2 * ks + hl) ^ kswz) << 4));
 #pragma unroll
-            for (int t = 0; t < 6; t += 2) {
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t]], qf[PQ[t]][ks], sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t + 1]], qf[PQ[t + 1]][ks], sb, 0, 0, 0);
-            }
+            for (int t = 0; t < 6; ++t) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PK[t]], qf[PQ[t]][ks], sa, 0, 0, 0);
         }
     };
 
@@ -225,10 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
         load_k(kt0 + 2, kr);
         load_v(kt0 + 1, vr);
         __syncthreads();
-        f32x16 sb;
-        s_tile(0, sc, sb);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] += sb[r];
+        s_tile(0, sc);
         __syncthreads();  // (K slot 0 is rewritten in the first tile's phase B: every wave must have read K(0) out)
     }
 
@@ -265,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
             }
         }
         // ---- phase A: the next tile's scores beside this tile's probabilities
-        f32x16 sn, sm;
-        if constexpr (WITH_S) s_tile(SLOT ^ 1, sn, sm);
+        f32x16 sn;
+        if constexpr (WITH_S) s_tile(SLOT ^ 1, sn);
         const float mref = fmaxf(mrun, -1e30f);  // (all keys masked so far: 2^(-inf - mref) = 0, not NaN)
         float psum = 0.0f;
 #pragma unroll
@@ -311,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_pl_kernel(const float* __
         load_v(kt + 2, vr);
         if constexpr (WITH_S) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = sn[r] + sm[r];
+            for (int r = 0; r < 16; ++r) sc[r] = sn[r];
         }
         __syncthreads();
     };
