@@ -70,3 +70,12 @@ done
 { tools/bin/tr_read_probe; tools/bin/soffset_bounds_probe; } > $out/${tag}_hw_rule_probes.txt 2>&1
 { for a in "8192 3072 768" "8192 3072 2304" "8192 4096 4096"; do tools/bin/gemm_bench $a -k s4 -nocheck 2>&1 | grep "^time"; done; tools/bin/gemm_bench 8192 3072 2304 -k s4 -nocheck -fill 1 2>&1 | grep "^time"; tools/bin/gemm_bench 8192 3072 768 -k s4 -nocheck -nogelu 2>&1 | grep "^time"; } > $out/${tag}_gemm_shapes.txt
 ls -la $out
+# round 5, second half: the prompt attention alone (timing, counters, workgroup timeline from the stamps build), the fp32-weight
+# pass at 8 prompts, the epilogue / ping-pong microbenchmarks
+{ for b in 8 4 2 1; do python3 tools/bench_attn_prefill.py $b 1023 12 2>/dev/null | tail -1; done; } > $out/${tag}_attn_prefill.jsonl
+python tools/bench_prefill.py --weights-f32 --batch 8 --lengths 1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
+python tools/bench_prefill.py --batch 4 --lengths 1023 >> $out/${tag}_prefill.jsonl 2>> $out/prefill.err
+if [ -f zig_gpt2_amd/lib/libzgpt2_hip_stamps.so ]; then ZGPT2_LIB=zig_gpt2_amd/lib/libzgpt2_hip_stamps.so python3 tools/attn_timeline.py 8 1023 12 > $out/${tag}_attn_timeline_8x1023.txt 2>/dev/null; fi
+tools/bin/epilogue_issue > $out/${tag}_epilogue_issue.txt 2>&1
+tools/bin/pingpong_probe > $out/${tag}_pingpong_probe.txt 2>&1
+ls -la $out
