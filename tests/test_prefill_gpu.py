@@ -197,6 +197,35 @@ def test_prefill_124m_full_context_equals_decode_loop(zg):
     b.close()
 
 
+@pytest.mark.parametrize("weights_f32", [False, True])
+def test_prefill_124m_eight_full_prompts_equal_one_prompt_passes(zg, weights_f32):
+    """BASELINE config 3's prompt side at full size: eight 1023-token prompts in one pass — every Linear on the persistent
+    four-wave GEMM (three / six plane pairs in one K loop, K slices + reduce, the stream-K hand-over of c_attn's 384 tiles at its
+    real geometry), whole-row attention — against the same prompts passed one at a time, which run the 128-row GEMM family and
+    split key ranges: last-position logits and the decode step on top of the caches, rows 0, 3 and 7."""
+    cfg = synth.CONFIGS["124M"]
+    w = synth.make_weights(cfg, seed=5, bf16=not weights_f32)
+    n = cfg.context_size - 1
+    toks = np.stack([synth.rand_tokens(790 + b, n + 1, cfg.vocab_size) for b in range(8)])
+    m8 = zgpt.GPT(cfg, batch=8, weights_f32=weights_f32)
+    m8.load_weights(w)
+    before = zg.zg_debug_gemm_launches()
+    lg8 = m8.prefill(toks[:, :n]).copy()
+    assert zg.zg_debug_gemm_launches() - before >= 4 * cfg.n_layer, "the whole-prompt Linears did not run on gemm_s4"
+    nxt8 = m8.forward(n + 1, toks[:, n]).copy()
+    m8.close()
+    assert np.isfinite(lg8).all() and np.isfinite(nxt8).all()
+    m1 = zgpt.GPT(cfg, weights_f32=weights_f32)
+    m1.load_weights(w)
+    for b in (0, 3, 7):
+        before = zg.zg_debug_gemm_launches()
+        lg1 = m1.prefill([toks[b, :n]])
+        assert zg.zg_debug_gemm_launches() == before, "a single prompt was expected on the 128-row GEMM family"
+        assert_model_close(lg1[0], lg8[b], f"124M 8 x 1023 row {b} vs single pass (fp32 weights: {weights_f32})")
+        assert_model_close(m1.forward(n + 1, [toks[b, n]])[0], nxt8[b], f"124M decode after 8 x 1023 row {b} (fp32 weights: {weights_f32})")
+    m1.close()
+
+
 def test_prefill_errors(zg):
     cfg = synth.CONFIGS["tiny"]
     m = zgpt.GPT(cfg)
