@@ -375,14 +375,35 @@ __global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const float* __
     if (n == 1) return;
     const float* pp = part + rec * max_s * 66;
     float m = -INFINITY;
-    for (int s = 0; s < n; ++s) m = fmaxf(m, pp[s * 66 + 64]);
     f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
     float l = 0.0f;
-    for (int s = 0; s < n; ++s) {
-        const float w = __builtin_amdgcn_exp2f(pp[s * 66 + 64] - m);
-        l += w * pp[s * 66 + 65];
-        const float2 a = *reinterpret_cast<const float2*>(pp + s * 66 + d), c = *reinterpret_cast<const float2*>(pp + s * 66 + d + 2);
-        o.x += w * a.x; o.y += w * a.y; o.z += w * c.x; o.w += w * c.y;
+    if (n <= 8) {
+        // every load of the (up to eight) ranges issued before the first use: a loop over n with the maximum threaded through it
+        // waits for each range's record in turn — 2 n dependent round trips, 7.4 us per launch at one 1023-token prompt
+        float2 ml[8], a[8], c[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float* r = pp + (s < n ? s : 0) * 66;
+            ml[s] = *reinterpret_cast<const float2*>(r + 64);
+            a[s] = *reinterpret_cast<const float2*>(r + d);
+            c[s] = *reinterpret_cast<const float2*>(r + d + 2);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) m = s < n ? fmaxf(m, ml[s].x) : m;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float w = s < n ? __builtin_amdgcn_exp2f(ml[s].x - m) : 0.0f;
+            l += w * ml[s].y;
+            o.x += w * a[s].x; o.y += w * a[s].y; o.z += w * c[s].x; o.w += w * c[s].y;
+        }
+    } else {
+        for (int s = 0; s < n; ++s) m = fmaxf(m, pp[s * 66 + 64]);
+        for (int s = 0; s < n; ++s) {
+            const float w = __builtin_amdgcn_exp2f(pp[s * 66 + 64] - m);
+            l += w * pp[s * 66 + 65];
+            const float2 a = *reinterpret_cast<const float2*>(pp + s * 66 + d), c = *reinterpret_cast<const float2*>(pp + s * 66 + d + 2);
+            o.x += w * a.x; o.y += w * a.y; o.z += w * c.x; o.w += w * c.y;
+        }
     }
     const float inv = 1.0f / l;
     store_split4(out + ((size_t)b * P + q) * kSplit * E + h * 64 + d, E, f32x4{o.x * inv, o.y * inv, o.z * inv, o.w * inv});
