@@ -421,6 +421,24 @@ __global__ __launch_bounds__(256, 1) void prefill_gemm_wp_kernel(const bf16_t* _
     else prefill_gemm_body<PF_PARTIAL, NS, 1>(A, B + 2 * plane, bias, C, M, N, K, ldc, tp, n_tiles, qa, sp, slab);
 }
 
+// Four columns of one row summed over the K-slice slabs, in slab order.  The loads go out four slabs at a time before the
+// first addition: a loop that adds as it loads waits for every slab's round trip in turn (a one-prompt residual Linear has 4-5
+// slabs, an fp32-weight one up to 12: the reduce kernel took 7-8 us of which the loads' latencies were most).
+__device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ ws, int n_sp, int M, int N, int row, int col) {
+    const size_t slab = (size_t)M * N;
+    const float* p = ws + (size_t)row * N + col;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    for (int sp0 = 1; sp0 < n_sp; sp0 += 4) {
+        f32x4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(sp0 + u < n_sp ? sp0 + u : 0) * slab);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (sp0 + u < n_sp) a += t[u];
+    }
+    return a;
+}
+
 // Second half of a split-K GEMM: sum the slices in fixed order (deterministic), add bias, apply the epilogue.
 template <int EPI>
 __global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __restrict__ ws, int n_sp,
@@ -430,8 +448,7 @@ __global__ __launch_bounds__(256) void prefill_reduce_kernel(const float* __rest
     const int n4 = N / 4;
     if (i >= (size_t)M * n4) return;
     const int m = (int)(i / n4), n = (int)(i % n4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
-    for (int sp = 1; sp < n_sp; ++sp) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)sp * M + m) * N + n);
+    f32x4 v = sum_slabs(ws, n_sp, M, N, m, n);
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
     if (EPI == PF_GELU_SPLIT) {
         v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w);
@@ -464,10 +481,11 @@ __global__ __launch_bounds__(256) void prefill_reduce_resid_ln_kernel(const floa
         v[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (i < n4) {
             const int e = i * 4;
-            f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)row * N + e);
-            for (int sp = 1; sp < n_sp; ++sp) a += *reinterpret_cast<const f32x4*>(ws + ((size_t)sp * M + row) * N + e);
-            if (bias) a += *reinterpret_cast<const f32x4*>(bias + e);
-            a += *reinterpret_cast<const f32x4*>(xr + e);
+            const f32x4 res = *reinterpret_cast<const f32x4*>(xr + e);
+            const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + e) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 a = sum_slabs(ws, n_sp, M, N, row, e);
+            if (bias) a += bv;
+            a += res;
             *reinterpret_cast<f32x4*>(xr + e) = a;
             v[j] = a;
             s += (a.x + a.y) + (a.z + a.w);
