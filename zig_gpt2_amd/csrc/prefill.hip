@@ -670,12 +670,22 @@ static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws
     if (epi != PF_RESID) return tiles >= min_tiles ? 1 : 0;
     if (!have_ws) return 0;
     // (at most four slices: a one-prompt mlp c_proj cut into twelve — 16 tiles — ran 21.8 + 8.0 us of GEMM + reduce against 15.5 + 6.8
-    // on the 128-row kernel: profiles/round5_prefill_1x1023_kernel_stats.md of the first pass)
-    for (int n_sl = 1; n_sl <= kpp / 2 && (n_sl <= 4 || g_force_slices > 0); ++n_sl) {
+    // on the 128-row kernel: profiles/round5_prefill_1x1023_kernel_stats.md of the first pass).  Among the slice counts that divide
+    // the K-steps: the one whose items fill most of ONE round of 256 workgroups (four prompts: 64 tiles x 4 rather than x 3); more
+    // tiles than that run unsliced.
+    if (g_force_slices > 0) return (kpp % g_force_slices == 0 && g_force_slices <= kpp / 2 && (size_t)g_force_slices * M * N <= ws_floats) ? g_force_slices : 0;
+    int best = 0;
+    long best_items = 0;
+    for (int n_sl = 1; n_sl <= 4 && n_sl <= kpp / 2; ++n_sl) {
         if (kpp % n_sl != 0 || (size_t)n_sl * M * N > ws_floats) continue;
-        if (g_force_slices > 0 ? n_sl == g_force_slices : tiles * n_sl >= min_tiles) return n_sl;
+        const long items = tiles * n_sl;
+        if (items < min_tiles) continue;
+        if (best == 0 || (items <= 256 && items > best_items)) {
+            best = n_sl;
+            best_items = items;
+        }
     }
-    return 0;
+    return best;
 }
 
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
