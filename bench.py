@@ -361,30 +361,68 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    def all_ranks_ok(ok):  # every rank takes the same branch: the native path only if it worked everywhere
+        if not use_dist:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    native_ok = False
     try:
         uid = (C.c_ubyte * 128)()
+        err = None
         if rank == 0:
-            _lib.check(lib.zg_dist_unique_id(uid, 128))
+            try:
+                _lib.check(lib.zg_dist_unique_id(uid, 128))
+            except _lib.ZgError as e:
+                err = str(e)
         if use_dist:
-            box = [bytes(uid)]
+            box = [None if err else bytes(uid), err]
             dist.broadcast_object_list(box, src=0)
-            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
-        _lib.check(lib.zg_dist_init(uid, 128, rank, world))
+            err = box[1]
+            if err is None:
+                uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        if err is not None:
+            raise _lib.ZgError(err)
+        ok = True
+        try:
+            _lib.check(lib.zg_dist_init(uid, 128, rank, world))
+        except _lib.ZgError as e:
+            ok, err = False, str(e)
+        if not all_ranks_ok(ok):
+            raise _lib.ZgError(err or "zg_dist_init failed on another rank")
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         ms = C.c_float(0.0)
-        _lib.check(lib.zg_gpt_broadcast_weights(model.h, 0, C.byref(ms)))
+        try:
+            _lib.check(lib.zg_gpt_broadcast_weights(model.h, 0, C.byref(ms)))
+        except _lib.ZgError as e:
+            ok, err = False, str(e)
+        if not all_ranks_ok(ok):
+            raise _lib.ZgError(err or "zg_gpt_broadcast_weights failed on another rank")
         bcast_ms = float(ms.value)
         _lib.check(lib.zg_dist_finalize())
+        native_ok = True
     except _lib.ZgError as e:
-        if world > 1:
-            raise
-        bcast_note = str(e)  # (a one-GPU box without librccl: nothing to broadcast to)
+        bcast_note = f"native RCCL path unavailable ({e})"  # (a one-GPU box without librccl: nothing to broadcast to)
     finally:
         C.CDLL(None).fflush(None)
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
+    if not native_ok and world > 1:
+        # the run must still measure the step: the same weight region through torch.distributed's broadcast (RCCL as well), and
+        # the line says so
+        ptr, nbytes = model.weight_arena()
+        arena = torch.as_tensor(_DevMem(ptr, nbytes), device=torch.device("cuda", local_rank))
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
+        shard.broadcast_weights(arena, dist, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - tb) * 1e3
+        bcast_note += "; weights broadcast by torch.distributed.broadcast over the same arena region (host wall clock)"
     setup_s = time.perf_counter() - t0
 
     # ---- prompts: one token each, distinct per global prompt index
