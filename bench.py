@@ -576,6 +576,11 @@ def main():
             "l2_prefetcher": ("stalled" if pf["stalled"] else "on") if pf["on"] else "off",
             "parallelism": f"replicated weights, prompts sharded x{world}, RCCL broadcast at start-up only",
             "tokens_counted": "generated tokens (context - prompt) per prompt",
+            "scaling_note": ("N = 1 runs BASELINE configs[1] (one prompt: the headline metric); N > 1 runs configs[2] (8 prompts per GPU, "
+                             "fixed per-GPU work for every N >= 2).  The one-GPU figure with THAT per-GPU work is other_configs[0].value of the "
+                             "N = 1 line (8 prompts on one GPU), which is what an N-GPU value divides by for a scaling efficiency; "
+                             "--prompts-per-gpu pins the per-GPU work for all N") if a.prompts_per_gpu == 0 else
+                            f"per-GPU work pinned by --prompts-per-gpu {ppg} for every N",
         },
         "roofline": {
             "kernel": dom["class"], "kernel_symbol": dom["kernel_symbol"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
