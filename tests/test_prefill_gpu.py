@@ -226,6 +226,39 @@ def test_prefill_124m_eight_full_prompts_equal_one_prompt_passes(zg, weights_f32
     m1.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_prefill_shape_sweep_against_the_oracle(zg, seed):
+    """Seeded sweep over (model, batch, prompt length, weight type, GEMM route): whatever the routing rules pick — 128-row kernels,
+    persistent GEMM with 1-4 K slices, whole-row or split-range attention, merge kernel — one row's last-position logits and
+    its next decode step against the oracle, and the other rows finite."""
+    rng = np.random.default_rng(9000 + seed)
+    name = ["tiny", "tiny3", "nano-char", "xl-slice", "medium-slice"][int(rng.integers(0, 5))]
+    cfg = synth.CONFIGS[name]
+    batch = int(rng.integers(1, 9))
+    n = int(rng.integers(1, min(cfg.context_size, 200)))
+    f32 = bool(rng.integers(0, 2))
+    route = int(rng.integers(0, 3))  # 0 the library's rule, 1 everything on gemm_s4, 2 everything on the 128-row kernels
+    w = synth.make_weights(cfg, seed=100 + seed, bf16=not f32)
+    m = zgpt.GPT(cfg, batch=batch, weights_f32=f32)
+    m.load_weights(w)
+    toks = np.stack([synth.rand_tokens(9100 + 13 * seed + b, n + 1, cfg.vocab_size) for b in range(batch)])
+    _lib.check(zg.zg_debug_prefill_route(route, 0))
+    try:
+        lg = m.prefill(toks[:, :n]).copy()
+    finally:
+        _lib.check(zg.zg_debug_prefill_route(0, 0))
+    nxt = m.forward(n + 1, toks[:, n]) if n < cfg.context_size else None
+    assert np.isfinite(lg).all()
+    b = int(rng.integers(0, batch))
+    what = f"sweep {seed}: {name} batch {batch} n {n} f32 {f32} route {route} row {b}"
+    lg_ref = oracle.GPT(cfg, w).forced_logits(toks[b], n - 1)
+    assert_model_close(lg_ref[0], lg[b], what)
+    if nxt is not None:
+        assert np.isfinite(nxt).all()
+        assert_model_close(lg_ref[1], nxt[b], what + " (decode step on top)")
+    m.close()
+
+
 def test_prefill_errors(zg):
     cfg = synth.CONFIGS["tiny"]
     m = zgpt.GPT(cfg)
