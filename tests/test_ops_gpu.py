@@ -151,11 +151,13 @@ def test_linear_wider_than_the_four_wave_gemm_arguments(zg):
     assert_ref_close(oracle.linear_forward(k, 130, w130, None, x), y130, f"Linear {m}x{k}x130 (K chunks)", scale_floor=2e-6)
 
 
-@pytest.mark.parametrize("m,k,n,bias", [(1, 8200, 37, True), (3, 12328, 70, True), (9, 20000, 16, False), (2, 16384, 2100, True)])
+@pytest.mark.parametrize("m,k,n,bias", [(1, 8200, 37, True), (3, 12328, 70, True), (9, 20000, 16, False), (2, 16384, 2100, True),
+                                        (2, 8771, 37, True), (5, 16389, 70, False), (17, 9001, 24, True)])
 def test_linear_wider_than_8192_runs_in_k_chunks(zg, m, k, n, bias):
     """Linear.forward has no size limit (src/ops.zig:21-46): in_features beyond the 8192 the GEMV kernels hold in LDS runs as K chunks
     (chunk 0 with the bias, later chunks through the residual epilogue onto the same rows; W in row blocks of 2048 for the 2100-row
-    case); batch 9 = two row groups."""
+    case); batch 9 = two row groups.  in_features that is not a multiple of 8 (found by tools/fuzz_ops.py): the ragged chunk runs first,
+    on the plain store epilogue — the accumulating epilogue takes whole chunks only."""
     w = synth.fill_normal(100 + n, n * k, 0, 0.02).reshape(n, k)
     b = synth.fill_normal(200 + n, n, 0, 0.05) if bias else None
     x = synth.fill_normal(300 + m, m * k, 0, 1.0).reshape(m, k)

@@ -220,8 +220,11 @@ static int linear_device_wide(Call& call, size_t in_f, size_t out_f, const float
     ZG_TRY(call.scratch(8 * kc_max, &xc));
     for (size_t m0 = 0; m0 < m; m0 += 8) {
         const size_t mb = m - m0 < 8 ? m - m0 : 8;
-        for (size_t k0 = 0; k0 < in_f; k0 += kc_max) {
-            const size_t kc = in_f - k0 < kc_max ? in_f - k0 : kc_max;
+        // (the ragged chunk goes FIRST: only the plain store epilogue of the GEMV kernels takes a K that is not a multiple of 8,
+        // the accumulating chunks behind it are whole — tools/fuzz_ops.py found in_features = 8192 j + 579 failing the other way round)
+        const size_t first = in_f % kc_max ? in_f % kc_max : kc_max;
+        for (size_t k0 = 0; k0 < in_f; k0 += (k0 == 0 ? first : kc_max)) {
+            const size_t kc = k0 == 0 ? first : kc_max;
             ZG_HIP(hipMemcpy2DAsync(xc, kc * 4, x + m0 * in_f + k0, in_f * 4, kc * 4, mb, hipMemcpyDeviceToDevice, s));
             for (size_t n0 = 0; n0 < out_f; n0 += rows) {
                 const size_t nb = out_f - n0 < rows ? out_f - n0 : rows;
