@@ -124,7 +124,9 @@ int zg_softmax(float* inputs, size_t inputs_len);
  * optional fused GELU — the same contraction as Linear.forward's cblas_sgemm(NoTrans, Trans)
  * (src/ops.zig:30-45) for large batch (prefill), with both operands in ops.Linear's K-contiguous
  * layouts.  A, B are bf16 bit patterns and C is bf16 (out_bf16 != 0) or fp32, all DEVICE pointers;
- * any M; N a multiple of 8 for bf16 C, any N for fp32 C; K a multiple of 64 and at least 128.  Asynchronous on
+ * any M; N a multiple of 8 for bf16 C, any N for fp32 C (an N that is not a multiple of 4 is stored by the four-wave kernel
+ * only, whose packed arguments end at K = 16320: beyond that ZG_ERR_UNSUPPORTED — zg_linear_forward, which has no such limit,
+ * takes such a Linear through its GEMV kernels); K a multiple of 64 and at least 128.  Asynchronous on
  * the library stream.  zg_linear_forward itself takes this path for batch >= 16 (fp32 operands split
  * exactly into bf16 planes, so the result stays fp32-sgemm grade).
  * zg_f32_to_bf16 converts a device or host fp32 array into a device bf16 array (round to nearest even). */
