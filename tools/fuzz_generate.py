@@ -2,7 +2,7 @@
 """Random generate() configurations against the oracle's greedy loop: model, batch, ragged prompt lengths, steps, KV cache type
 (fp32 / 24-bit: ids must match; fp16 is outside the bound and not swept), weight type, graph on / off, whole-prompt pass on / off,
 L2 prefetcher on / off.  A differing id is accepted only at a numerical tie of the oracle's own top two logits (golden_io).
-python tools/fuzz_generate.py [first_seed] [count]"""
+python tools/fuzz_generate.py [first_seed] [count] [max_steps = 96]"""
 import os, sys, traceback
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
@@ -12,7 +12,7 @@ from golden_io import assert_greedy_ids_match
 from zig_gpt2_amd import _lib, gpt as zgpt, synth
 
 zg = _lib.load(); _lib.check(zg.zg_init(0))
-first, count = (int(v) for v in (sys.argv[1:3] + ["0", "60"][len(sys.argv) - 1:]))
+first, count, max_steps = (int(v) for v in (sys.argv[1:4] + ["0", "60", "96"][len(sys.argv) - 1:]))
 bad = []
 for seed in range(first, first + count):
     rng = np.random.default_rng(5000 + seed)
@@ -22,7 +22,7 @@ for seed in range(first, first + count):
     f32 = bool(rng.integers(0, 3) == 0)
     kw = dict(weights_f32=f32, use_graph=bool(rng.integers(0, 4)), kv_b24=bool(rng.integers(0, 3) == 0), prefill=bool(rng.integers(0, 2)),
               prefetch=bool(rng.integers(0, 2)))
-    n_steps = int(rng.integers(2, min(cfg.context_size, 96) + 1))
+    n_steps = int(rng.integers(2, min(cfg.context_size, max_steps) + 1))
     lens = [int(rng.integers(1, max(2, min(n_steps, 40)))) for _ in range(batch)]
     prompts = [synth.rand_tokens(5100 + 17 * seed + b, lens[b], cfg.vocab_size) for b in range(batch)]
     what = f"seed {seed}: {name} batch {batch} steps {n_steps} lens {lens} {kw}"
