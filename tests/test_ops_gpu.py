@@ -301,3 +301,18 @@ def test_error_behaviour(zg):
         ops.Embedding(8, z(4, 8)).forward(np.array([5], np.uint64), z(8))  # index out of range
     with pytest.raises(_lib.ZgError):
         ops.scaled_dot_product_attention(z(32), z(32), z(32), 1, 1, 32, z(32), z(1))  # head_dim != 64
+
+
+def test_null_slices_are_refused_not_dereferenced(zg):
+    """A NULL pointer with a non-empty length is an argument error on every op (found by tools/fuzz_errors.py: Linear's outputs,
+    Embedding's embeddings, split_qkv's and transpose's slices reached a kernel — a GPU memory fault takes the process down)."""
+    x, w = z(64), z(4, 8)
+    ERR_ARG = -6
+    assert zg.zg_linear_forward(8, 4, w.ctypes.data, None, x.ctypes.data, 8, None, 4) == ERR_ARG
+    idx = np.zeros(2, np.uint64)
+    assert zg.zg_embedding_forward(8, w.ctypes.data, 32, idx.ctypes.data, 2, None, 16) == ERR_ARG
+    assert zg.zg_split_qkv(8, 1, None, 24, 0, x.ctypes.data, 8) == ERR_ARG
+    assert zg.zg_split_qkv(8, 1, x.ctypes.data, 24, 0, None, 8) == ERR_ARG
+    assert zg.zg_transpose(1, 1, 8, None, 8, x.ctypes.data, 8) == ERR_ARG
+    assert zg.zg_transpose(1, 1, 8, x.ctypes.data, 8, None, 8) == ERR_ARG
+    assert zg.zg_linear_forward(8, 4, w.ctypes.data, None, x.ctypes.data, 8, x.ctypes.data, 4) == 0  # (and the library carries on)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Edge and nonsense arguments through the op tier of the C ABI: zero lengths, zero dimensions, lengths that do not divide,
+null pointers, a sequence length of 0, head counts that do not divide — every call must RETURN (ZG_OK or an error code with a
+message), never crash or hang, and the library must keep working afterwards.  python tools/fuzz_errors.py [seed] [count]"""
+import ctypes as C, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import numpy as np
+from zig_gpt2_amd import _lib, ops, synth
+
+zg = _lib.load(); _lib.check(zg.zg_init(0))
+seed, count = (int(v) for v in (sys.argv[1:3] + ["0", "400"][len(sys.argv) - 1:]))
+rng = np.random.default_rng(seed)
+buf = [np.zeros(1 << 21, np.float32) for _ in range(8)]  # (large enough for every weight shape below: lengths the ABI cannot check must not lie)
+idx = np.zeros(64, np.uint64)
+P = lambda a: a.ctypes.data
+def size():
+    return int(rng.choice([0, 0, 1, 2, 3, 7, 8, 63, 64, 65, 100, 128, 192, 255, 256, 1000, 4096, int(rng.integers(0, 1 << 16))]))
+def ptr(i):
+    return None if rng.integers(0, 12) == 0 else P(buf[i])
+codes = {}
+only = int(os.environ.get("ONLY", "-1"))
+for it in range(count):
+    k = int(rng.integers(0, 9))
+    if only >= 0: k = only
+    if os.environ.get("TRACE"): print("call", it, "kind", k, flush=True)
+    if k == 0:
+        i_f, o_f = size(), size()
+        if i_f * o_f > (1 << 21): o_f = (1 << 21) // max(i_f, 1)
+        r = zg.zg_linear_forward(i_f, o_f, ptr(0), ptr(1), ptr(2), size(), ptr(3), size())
+    elif k == 1: r = zg.zg_embedding_forward(size(), ptr(0), size(), P(idx) if rng.integers(0, 10) else None, int(rng.integers(0, 65)), ptr(1), size())
+    elif k == 2: r = zg.zg_layernorm_forward(size(), ptr(0), ptr(1), 1e-5, ptr(2), size())
+    elif k == 3:
+        h, e = int(rng.choice([0, 1, 2, 3, 12, 16])), int(rng.choice([0, 64, 128, 100, 192, 768]))
+        t = int(rng.choice([0, 1, 2, 5, 40]))
+        r = zg.zg_attn_forward(h, e, ptr(0), ptr(1), ptr(2), ptr(3), t, ptr(4), size(), ptr(5), size(), ptr(6), size(), ptr(7), size(),
+                               ptr(4), size(), ptr(5), size(), ptr(6), size(), ptr(7), size(), ptr(4), size())
+    elif k == 4: r = zg.zg_split_qkv(size(), int(rng.choice([0, 1, 5])), ptr(0), size(), int(rng.integers(0, 5)), ptr(1), size())
+    elif k == 5: r = zg.zg_transpose(int(rng.choice([0, 1, 5])), int(rng.choice([0, 1, 12])), int(rng.choice([0, 1, 64])), ptr(0), size(), ptr(1), size())
+    elif k == 6: r = zg.zg_scaled_dot_product_attention(ptr(0), size(), ptr(1), size(), ptr(2), size(), int(rng.choice([0, 1, 12])), int(rng.choice([0, 1, 7])),
+                                                         int(rng.choice([0, 32, 64])), ptr(3), size(), ptr(4), size())
+    elif k == 7: r = zg.zg_gelu(ptr(0), size())
+    else: r = zg.zg_softmax(ptr(0), size())
+    codes[r] = codes.get(r, 0) + 1
+    if r != 0: assert len(zg.zg_last_error()) > 0
+# the library still computes
+w = synth.fill_normal(1, 64 * 32, 0, 0.1).reshape(32, 64); x = synth.fill_normal(2, 64, 0, 1.0); y = np.zeros(32, np.float32)
+ops.Linear(64, 32, w, None).forward(x, y)
+assert np.abs(y - w @ x).max() < 1e-5
+print(f"{count} calls returned; status histogram {dict(sorted(codes.items()))}; the library still computes")

@@ -397,6 +397,7 @@ int zg_linear_forward(size_t in_features, size_t out_features, const float* weig
     ZG_TRY(require_init());
     ZG_REQUIRE(in_features > 0 && weight && (inputs || inputs_len == 0), ZG_ERR_ARG, "Linear: null argument");
     const size_t batch = inputs_len / in_features;  // ops.zig:22
+    ZG_REQUIRE(outputs || batch * out_features == 0, ZG_ERR_ARG, "Linear: null outputs");
     ZG_REQUIRE(inputs_len == batch * in_features, ZG_ERR_SHAPE,
                "Linear: inputs.len %zu is not a multiple of in_features %zu", inputs_len, in_features);
     ZG_REQUIRE(outputs_len >= batch * out_features, ZG_ERR_SHAPE,
@@ -487,7 +488,7 @@ int zg_f32_to_bf16(const float* src, uint16_t* dst_device, size_t len) {
 int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len, const size_t* idxs,
                          size_t idxs_len, float* embeddings, size_t embeddings_len) {
     ZG_TRY(require_init());
-    ZG_REQUIRE(emb_dim > 0 && weight && (idxs || idxs_len == 0), ZG_ERR_ARG, "Embedding: null argument");
+    ZG_REQUIRE(emb_dim > 0 && weight && (idxs || idxs_len == 0) && (embeddings || idxs_len == 0), ZG_ERR_ARG, "Embedding: null argument");
     ZG_REQUIRE(embeddings_len >= idxs_len * emb_dim, ZG_ERR_SHAPE,
                "Embedding: embeddings.len %zu < %zu indices * emb_dim %zu", embeddings_len, idxs_len, emb_dim);
     Call call;
@@ -559,6 +560,7 @@ int zg_split_qkv(size_t n_embed, size_t seq_len, const float* inputs, size_t inp
     ZG_REQUIRE(n_embed > 0 && seq_len > 0 && split_idx < 3, ZG_ERR_ARG, "split_qkv: bad argument");
     const size_t batch = inputs_len / (seq_len * 3 * n_embed);  // ops.zig:185
     const size_t rows = batch * seq_len;
+    ZG_REQUIRE(rows == 0 || (inputs && outputs), ZG_ERR_ARG, "split_qkv: null argument");
     ZG_REQUIRE(outputs_len >= rows * n_embed, ZG_ERR_SHAPE, "split_qkv: outputs.len %zu < %zu", outputs_len,
                rows * n_embed);
     Call call;
@@ -579,6 +581,7 @@ int zg_transpose(size_t seq_len, size_t n_heads, size_t head_dim, const float* i
     const size_t per = seq_len * n_heads * head_dim;
     ZG_REQUIRE(per > 0, ZG_ERR_ARG, "transpose: empty shape");
     const size_t batch = inputs_len / per;  // ops.zig:203
+    ZG_REQUIRE(batch == 0 || (inputs && outputs), ZG_ERR_ARG, "transpose: null argument");
     ZG_REQUIRE(outputs_len >= batch * per, ZG_ERR_SHAPE, "transpose: outputs.len %zu < %zu", outputs_len, batch * per);
     ZG_REQUIRE(n_heads <= 65535 && batch <= 65535, ZG_ERR_UNSUPPORTED, "transpose: n_heads/batch > 65535");
     Call call;
