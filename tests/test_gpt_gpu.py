@@ -331,3 +331,26 @@ def test_batched_weight_load_shapes_agree(zg, monkeypatch, name):
         for o in outs:
             assert_greedy_ids_match(ref[len(p):], o[b, len(p):], top[:, -1], top[:, -2], f"{name} row {b}")
 
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_nan_in_the_weights_yields_tokens_not_a_gpu_fault(zg, batch):
+    """A NaN (or an overflow to inf) in a checkpoint makes every logit NaN: no comparison holds, and the greedy pick used to keep its
+    start value 0x7fffffff, which the next step's embedding gather followed out of the table — a GPU memory fault that takes the
+    process down (found by tools/fuzz_errors_gpt.py).  Now: index 0 for the greedy pick (what a loop starting at logits[0] keeps),
+    the last index for the sampler; ids stay inside the vocabulary and the handle keeps working once the weights are repaired."""
+    cfg = synth.CONFIGS["tiny"]
+    w = synth.make_weights(cfg, seed=1, bf16=True)
+    bad = dict(w)
+    bad["h0.c_fc_w"] = w["h0.c_fc_w"].copy()
+    bad["h0.c_fc_w"][3, 5] = np.nan
+    m = zgpt.GPT(cfg, batch=batch)
+    m.load_weights(bad)
+    ids = m.generate([[1, 2, 3]] * batch, 40)
+    assert (ids < cfg.vocab_size).all() and (ids[:, 3:] == 0).all()
+    tok = m.sample(4, [1] * batch, 0.8, seed=3)
+    assert (np.asarray(tok) < cfg.vocab_size).all()
+    m.load_weights(w)
+    ref = oracle.GPT(cfg, w).generate_greedy(np.array([1, 2, 3], np.uint64), 40)
+    assert np.array_equal(m.generate([[1, 2, 3]] * batch, 40)[0], ref)
+    m.close()

@@ -34,7 +34,8 @@ B = 3
 m = zgpt.GPT(cfg, batch=B)
 m.load_weights(w)
 V, ctx = cfg.vocab_size, cfg.context_size
-tok = np.zeros(64 * B, np.uint64); lg = np.zeros(B * V, np.float32); out = np.zeros(B * ctx, np.uint64); lens = np.ones(B, np.uint64)
+tok = np.zeros(64 * B, np.uint64); lg = np.zeros(B * V, np.float32); big = np.full(3 * cfg.n_embed * cfg.n_embed + V * cfg.n_embed, np.nan, np.float32)  # (NaN weights must not fault either)
+out = np.zeros(B * ctx, np.uint64); lens = np.ones(B, np.uint64)
 p = lambda a: a.ctypes.data
 def tokens():
     t = tok.copy()
@@ -43,19 +44,28 @@ def tokens():
 for it in range(count):
     k = int(rng.integers(0, 7))
     t = tokens()
+    if os.environ.get("TRACE"): print("call", it, "kind", k, flush=True)
     sl = int(rng.choice([0, 1, 2, ctx, ctx + 1, 1 << 33]))
     nt = int(rng.choice([0, 1, B - 1, B, B + 1]))
-    if k == 0: r = zg.zg_gpt_forward(m.h, sl, p(t) if rng.integers(0, 8) else None, nt, int(rng.integers(0, 2)), p(lg) if rng.integers(0, 3) else None, int(rng.choice([0, V, B * V])))
-    elif k == 1: r = zg.zg_gpt_prefill(m.h, p(t) if rng.integers(0, 8) else None, int(rng.choice([0, 1, 20, 64])), int(rng.choice([0, 1, 20, ctx, ctx + 1])), int(rng.integers(0, 2)),
-                                        p(lg) if rng.integers(0, 3) else None, int(rng.choice([0, V, B * V])))
+    if k == 0:
+        args = (sl, p(t) if rng.integers(0, 8) else None, nt, int(rng.integers(0, 2)), p(lg) if rng.integers(0, 3) else None, int(rng.choice([0, V, B * V])))
+        if os.environ.get("TRACE"): print("  forward", args[0], args[1] is not None, args[2:4], args[4] is not None, args[5], t[:B], flush=True)
+        r = zg.zg_gpt_forward(m.h, *args)
+    elif k == 1:
+        args = (p(t) if rng.integers(0, 8) else None, int(rng.choice([0, 1, 20, 64])), int(rng.choice([0, 1, 20, ctx, ctx + 1])), int(rng.integers(0, 2)),
+                p(lg) if rng.integers(0, 3) else None, int(rng.choice([0, V, B * V])))
+        if os.environ.get("TRACE"): print("  prefill", args[0] is not None, args[1:4], args[4] is not None, args[5], t[:B], flush=True)
+        r = zg.zg_gpt_prefill(m.h, *args)
     elif k == 2:
         lens[:] = [int(rng.choice([0, 1, 5, 21, ctx, ctx + 1])) for _ in range(B)]
-        r = zg.zg_gpt_generate_greedy(m.h, p(t) if rng.integers(0, 8) else None, int(rng.choice([0, 1, 21, 64])), p(lens) if rng.integers(0, 8) else None,
-                                      int(rng.choice([0, 1, 7, ctx, ctx + 1])), p(out) if rng.integers(0, 8) else None, int(rng.choice([0, B, B * ctx])))
+        args = (p(t) if rng.integers(0, 8) else None, int(rng.choice([0, 1, 21, 64])), p(lens) if rng.integers(0, 8) else None,
+                int(rng.choice([0, 1, 7, ctx, ctx + 1])), p(out) if rng.integers(0, 8) else None, int(rng.choice([0, B, B * ctx])))
+        if os.environ.get("TRACE"): print("  generate", args[0] is not None, args[1], args[2] is not None, args[3], args[4] is not None, args[5], lens, t[:B], flush=True)
+        r = zg.zg_gpt_generate_greedy(m.h, *args)
     elif k == 3: r = zg.zg_gpt_argmax(m.h, p(out) if rng.integers(0, 4) else None, nt)
     elif k == 4: r = zg.zg_gpt_sample(m.h, sl, p(t), nt, float(rng.choice([0.0, -1.0, 1.0, float("nan")])), None, 7, p(out), None, 0)
-    elif k == 5: r = zg.zg_gpt_load_tensor(m.h, int(rng.choice([-1, 0, 1, 3, 4, 99])), p(lg) if rng.integers(0, 4) else None, int(rng.choice([0, 7, V * cfg.n_embed])))
-    else: r = zg.zg_gpt_load_block_tensor(m.h, int(rng.choice([0, 1, 2, 99])), int(rng.choice([-1, 0, 2, 11, 12, 99])), p(lg) if rng.integers(0, 4) else None, int(rng.choice([0, 7, 3 * cfg.n_embed * cfg.n_embed])))
+    elif k == 5: r = zg.zg_gpt_load_tensor(m.h, int(rng.choice([-1, 0, 1, 3, 4, 99])), p(big) if rng.integers(0, 4) else None, int(rng.choice([0, 7, V * cfg.n_embed])))
+    else: r = zg.zg_gpt_load_block_tensor(m.h, int(rng.choice([0, 1, 2, 99])), int(rng.choice([-1, 0, 2, 11, 12, 99])), p(big) if rng.integers(0, 4) else None, int(rng.choice([0, 7, 3 * cfg.n_embed * cfg.n_embed])))
     note(r)
 # ---- (the load calls above may have replaced tensors with zeros: reload) the handle still computes the oracle's numbers
 m.load_weights(w)

@@ -40,6 +40,7 @@ struct zg_gpt {
     size_t wbytes;  // bytes per matrix element
     char* arena;
     size_t arena_bytes, weight_region_bytes;
+    size_t kv_region_bytes;  // the KV caches of all layers: one contiguous stretch of the arena from layers[0].k_cache
     void *wte, *wpe;
     float *ln_f_g, *ln_f_b;
     float *lm_c2, *lm_c3;  // ln_f folded out of lm_head (batched decode): wte g, wte b
@@ -164,6 +165,7 @@ void carve(zg_gpt* g, char* base) {
         g->layers[l].v_cache = P(B * C * E * kvb);
     }
     g->ctrl = (StepCtrl*)P(sizeof(StepCtrl));
+    g->kv_region_bytes = L ? (size_t)(reinterpret_cast<char*>(g->ctrl) - reinterpret_cast<char*>(g->layers[0].k_cache)) : 0;
     g->x = (float*)P(B * E * 4);
     g->q = (float*)P(B * E * 4);
     g->h4 = (float*)P(B * 4 * E * 4);
@@ -1051,6 +1053,16 @@ int zg_gpt_broadcast_weights(zg_gpt* g, int root, float* ms_out) {
     return ZG_OK;
 }
 
+// A new sequence starts (position 1 of the token-at-a-time loop, a whole-prompt pass, a generation): the caches are cleared.  The
+// decode attention loads the rows of its whole 64-position bucket and gives the ones at or behind the sequence length a
+// probability of exactly 0 — which silences any finite leftover of an earlier sequence, but 0 x NaN is NaN: once a sequence had
+// overflowed (or a checkpoint held a NaN) every later sequence on the handle came out NaN as well, repaired weights or not
+// (tools/fuzz_errors_gpt.py).  124M, one sequence: 75 MB, ~20 us per generation of 217 ms.
+static int clear_kv(zg_gpt* g, hipStream_t s) {
+    if (g->kv_region_bytes != 0 && g->arena != nullptr) ZG_HIP(hipMemsetAsync(g->layers[0].k_cache, 0, g->kv_region_bytes, s));
+    return ZG_OK;
+}
+
 int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* kv_bytes) {
     ZG_REQUIRE(g, ZG_ERR_ARG, "step_bytes: null argument");
     const size_t E = g->cfg.n_embed;
@@ -1081,6 +1093,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     g->h_ctrl->n_partials = g->lm_grid;
     ZG_HIP(hipMemcpyAsync(g->forced, g->h_ints, g->batch * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    if (seq_len == 1) ZG_TRY(clear_kv(g, s));
     ZG_TRY(note_steps(g, 1, s));
     ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(run_step(g, compute_logits != 0, seq_len, s));
@@ -1112,6 +1125,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
             g->h_ints[b * C + i] = (int)t;
         }
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
+    ZG_TRY(clear_kv(g, s));
     ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(enqueue_prefill(g, n_tokens, compute_logits != 0, s));
     if (compute_logits) {  // ln_f + lm_head of each sequence's last position through the decode kernels
@@ -1218,6 +1232,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
+    ZG_TRY(clear_kv(g, s));
     if (first > 0) {
         ZG_HIP(hipMemcpyAsync(g->out_tokens, g->prompt, B * C * sizeof(int), hipMemcpyDeviceToDevice, s));
         ZG_TRY(enqueue_prefill(g, first, false, s));

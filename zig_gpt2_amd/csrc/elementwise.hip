@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         }
         {   // the argument-block fields used behind the partial-maxima loads (zg_common.h ZG_PIN)
             ZG_PIN(a.forced); ZG_PIN(a.wte); ZG_PIN(a.wpe); ZG_PIN(a.weight_type); ZG_PIN(a.n_embed); ZG_PIN(a.cur_token); ZG_PIN(a.out_tokens);
-            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only); ZG_PIN(a.st_out);
+            ZG_PIN(a.out_stride); ZG_PIN(a.x); ZG_PIN(a.pl_out); ZG_PIN(a.pl_g); ZG_PIN(a.epoch); ZG_PIN(a.finish_only); ZG_PIN(a.st_out); ZG_PIN(a.vocab);
         }
         if (b == 0 && a.progress != nullptr && a.finish_only == 0 && lane == 0) {
             // a step at sequence length s + 1 starts; block 0 of every launch of this queue lands on the XCD this block is on
@@ -212,7 +212,10 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
         }
-        const int g = bi;
+        // logits that are all NaN compare false everywhere and leave the start value standing: index 0 then, as a loop that starts at
+        // logits[0] and keeps what compares greater (the oracle, and the reference's order of comparison) — never an index past
+        // the vocabulary, which the gather below would follow out of the table (a NaN in a checkpoint must not fault the GPU)
+        const int g = (unsigned)bi < (unsigned)a.vocab ? bi : 0;
         // the greedy pick of step s-1 exists iff that step ran lm_head (main.zig:337)
         const bool have_pick = a.finish_only == 2 || ((mode == 0) && (s >= 1) && (s - 1 >= np));
         if (lane == 0) {
@@ -326,6 +329,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(float* logits, int vocab, 
         }
         atomicMin(&token_out[blockIdx.x], pick);
     }
+    // probabilities that are NaN put the point in no thread's interval: the last index then, like a point at or past the total
+    __syncthreads();
+    if (tid == 0 && (unsigned)__hip_atomic_load(&token_out[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)vocab) token_out[blockIdx.x] = vocab - 1;
 }
 
 inline int grid_for(size_t n, int block = 256, int cap = 2048) {
