@@ -10,7 +10,25 @@ import numpy as np
 import oracle
 from zig_gpt2_amd import _lib, ops, synth
 
+import torch
 zg = _lib.load(); _lib.check(zg.zg_init(0))
+
+
+def place(a, rng, may_register=False):
+    """The array as the caller might hold it: host numpy, a device tensor, or (weights) a host array registered with the library."""
+    k = int(rng.integers(0, 3))
+    if a is None: return None
+    if k == 1:
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda(); torch.cuda.synchronize(); return t
+    if k == 2 and may_register:
+        _lib.check(zg.zg_register_tensor(a.ctypes.data, a.size))
+    return a
+
+
+def host(a):
+    return a.cpu().numpy() if hasattr(a, "cpu") else a
+
+
 first, count = (int(v) for v in (sys.argv[1:3] + ["0", "60"][len(sys.argv) - 1:]))
 bad = []
 for seed in range(first, first + count):
@@ -25,8 +43,9 @@ for seed in range(first, first + count):
             w = synth.fill_normal(seed * 7 + 1, in_f * out_f, 0, 0.05).reshape(out_f, in_f)
             bias = synth.fill_normal(seed * 7 + 2, out_f, 0, 0.1) if rng.integers(0, 4) else None
             x = synth.fill_normal(seed * 7 + 3, batch * in_f, 0, 1.0)
-            y = np.zeros(batch * out_f, np.float32)
-            ops.Linear(in_f, out_f, w, bias).forward(x, y)
+            y = place(np.zeros(batch * out_f, np.float32), rng)
+            ops.Linear(in_f, out_f, place(w, rng, True), place(bias, rng, True)).forward(place(x, rng), y)
+            torch.cuda.synchronize(); y = host(y); _lib.check(zg.zg_unregister_all())
             ref = x.reshape(batch, in_f).astype(np.float64) @ w.astype(np.float64).T + (0 if bias is None else bias.astype(np.float64))
             scale = np.abs(ref).max() + 1e-30
             err = np.abs(y.reshape(batch, out_f) - ref).max() / scale
@@ -38,7 +57,9 @@ for seed in range(first, first + count):
             x = synth.fill_normal(seed + 7, rows * n, 0.3, 2.0)
             ref = x.reshape(rows, n).astype(np.float64)
             ref = (ref - ref.mean(1, keepdims=True)) / np.sqrt(ref.var(1, keepdims=True) + 1e-5) * g + b
-            ops.LayerNorm(n, g, b).forward(x)
+            xd = place(x, rng)
+            ops.LayerNorm(n, place(g, rng, True), place(b, rng, True)).forward(xd)
+            torch.cuda.synchronize(); x = host(xd); _lib.check(zg.zg_unregister_all())
             what = f"LayerNorm n {n} rows {rows}"
             assert np.abs(x.reshape(rows, n) - ref).max() < 2e-5, what
         elif kind == 4:
@@ -46,7 +67,7 @@ for seed in range(first, first + count):
             x = synth.fill_normal(seed + 8, n, 0, 3.0)
             r = x.astype(np.float64)
             ref = 0.5 * r * (1 + np.tanh(np.sqrt(2 / np.pi) * (r + 0.044715 * r ** 3)))
-            ops.gelu(x)
+            xd = place(x, rng); ops.gelu(xd); torch.cuda.synchronize(); x = host(xd)
             what = f"gelu n {n}"
             assert np.abs(x - ref).max() < 2e-6, what
         elif kind == 6:  # CausalSelfAttention.forward over T incremental steps against the oracle's
@@ -96,7 +117,7 @@ for seed in range(first, first + count):
             n = int(rng.integers(1, 60000))
             x = synth.fill_normal(seed + 9, n, 0, 4.0)
             r = x.astype(np.float64); r = np.exp(r - r.max()); ref = r / r.sum()
-            ops.softmax(x)
+            xd = place(x, rng); ops.softmax(xd); torch.cuda.synchronize(); x = host(xd)
             what = f"softmax n {n}"
             assert np.abs(x - ref).max() < 1e-6 * max(1.0, ref.max() * 10), what
     except Exception:
