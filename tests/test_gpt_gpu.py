@@ -353,4 +353,19 @@ def test_nan_in_the_weights_yields_tokens_not_a_gpu_fault(zg, batch):
     m.load_weights(w)
     ref = oracle.GPT(cfg, w).generate_greedy(np.array([1, 2, 3], np.uint64), 40)
     assert np.array_equal(m.generate([[1, 2, 3]] * batch, 40)[0], ref)
+    # ... also through a whole-prompt pass (which clears only the rows behind the prompt) and a fresh token-at-a-time loop
+    m.load_weights(bad)
+    m.generate([[1, 2, 3]] * batch, 40)  # NaN rows in every cache again
+    m.load_weights(w)
+    toks = synth.rand_tokens(3, 40, cfg.vocab_size)
+    lg_ref = oracle.GPT(cfg, w).forced_logits(toks, 36)
+    assert_model_close(lg_ref[0], m.prefill([toks[:37]] * batch)[0], "prefill after a NaN run")
+    assert_model_close(lg_ref[1], m.forward(38, [toks[37]] * batch)[0], "decode step after that prefill")
+    m.load_weights(bad)
+    m.generate([[1, 2, 3]] * batch, 40)
+    m.load_weights(w)
+    lg = None
+    for st in range(38):
+        lg = m.forward(st + 1, [toks[st]] * batch, compute_logits=(st == 37))
+    assert_model_close(lg_ref[1], lg[0], "token-at-a-time loop after a NaN run")
     m.close()

@@ -1058,8 +1058,23 @@ int zg_gpt_broadcast_weights(zg_gpt* g, int root, float* ms_out) {
 // probability of exactly 0 — which silences any finite leftover of an earlier sequence, but 0 x NaN is NaN: once a sequence had
 // overflowed (or a checkpoint held a NaN) every later sequence on the handle came out NaN as well, repaired weights or not
 // (tools/fuzz_errors_gpt.py).  124M, one sequence: 75 MB, ~20 us per generation of 217 ms.
-static int clear_kv(zg_gpt* g, hipStream_t s) {
-    if (g->kv_region_bytes != 0 && g->arena != nullptr) ZG_HIP(hipMemsetAsync(g->layers[0].k_cache, 0, g->kv_region_bytes, s));
+// from_row > 0 (a whole-prompt pass writes rows 0 .. from_row - 1 itself): only the rows behind it, strip by strip — eight
+// 1023-token prompts would otherwise pay a 600 MB memset (0.12 ms of a 5.4 ms pass) for one stale row per head.
+static int clear_kv(zg_gpt* g, hipStream_t s, size_t from_row = 0) {
+    if (g->kv_region_bytes == 0 || g->arena == nullptr) return ZG_OK;
+    const size_t C = g->cfg.context_size, E = g->cfg.n_embed, B = g->batch, L = g->cfg.n_layer;
+    if (from_row == 0 || from_row * 2 < C) {
+        ZG_HIP(hipMemsetAsync(g->layers[0].k_cache, 0, g->kv_region_bytes, s));
+        return ZG_OK;
+    }
+    const size_t elems = B * C * E, kvb = g->kv_mode == 1 ? 2 : g->kv_mode == 2 ? 3 : 4;
+    const size_t stride = L > 1 ? (size_t)(reinterpret_cast<char*>(g->layers[1].k_cache) - reinterpret_cast<char*>(g->layers[0].k_cache)) / 2
+                                : (size_t)(reinterpret_cast<char*>(g->layers[0].v_cache) - reinterpret_cast<char*>(g->layers[0].k_cache));
+    ZG_REQUIRE(stride >= elems * kvb && reinterpret_cast<char*>(g->layers[0].v_cache) - reinterpret_cast<char*>(g->layers[0].k_cache) == (ptrdiff_t)stride,
+               ZG_ERR_UNSUPPORTED, "kv clear: cache stride");
+    const int strips = (int)(B * g->cfg.n_heads);
+    ZG_TRY(launch_kv_clear_tail(g->layers[0].k_cache, (int)(2 * L), stride, 0, g->kv_mode == 0 ? 256 : 128, strips, (int)C, (int)from_row, s));
+    if (g->kv_mode == 2) ZG_TRY(launch_kv_clear_tail(g->layers[0].k_cache, (int)(2 * L), stride, elems * 2, 64, strips, (int)C, (int)from_row, s));
     return ZG_OK;
 }
 
@@ -1125,7 +1140,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
             g->h_ints[b * C + i] = (int)t;
         }
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
-    ZG_TRY(clear_kv(g, s));
+    ZG_TRY(clear_kv(g, s, n_tokens));
     ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(enqueue_prefill(g, n_tokens, compute_logits != 0, s));
     if (compute_logits) {  // ln_f + lm_head of each sequence's last position through the decode kernels
@@ -1232,7 +1247,7 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
-    ZG_TRY(clear_kv(g, s));
+    ZG_TRY(clear_kv(g, s, first));
     if (first > 0) {
         ZG_HIP(hipMemcpyAsync(g->out_tokens, g->prompt, B * C * sizeof(int), hipMemcpyDeviceToDevice, s));
         ZG_TRY(enqueue_prefill(g, first, false, s));

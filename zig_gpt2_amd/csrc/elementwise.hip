@@ -414,6 +414,24 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
     return ZG_OK;
 }
 
+static __global__ __launch_bounds__(256) void kv_clear_tail_kernel(char* base, size_t cache_stride, size_t plane_off, int row_bytes, int strips, int ctx,
+                                                            int from_row) {
+    const int strip = blockIdx.x, cache = blockIdx.y;
+    char* p = base + (size_t)cache * cache_stride + plane_off + ((size_t)strip * ctx + from_row) * row_bytes;
+    const size_t n16 = (size_t)(ctx - from_row) * row_bytes / 16;  // (row_bytes is a multiple of 64)
+    for (size_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<u32x4*>(p)[i] = u32x4{0u, 0u, 0u, 0u};
+}
+
+int launch_kv_clear_tail(void* base, int n_caches, size_t cache_stride, size_t plane_off, int row_bytes, int strips, int ctx, int from_row,
+                         hipStream_t s) {
+    if (from_row >= ctx || n_caches == 0 || strips == 0) return ZG_OK;
+    ZG_REQUIRE(row_bytes % 64 == 0 && strips < 65536 * 32 && n_caches < 65536, ZG_ERR_UNSUPPORTED, "kv clear: %d-byte rows, %d strips", row_bytes, strips);
+    hipLaunchKernelGGL(kv_clear_tail_kernel, dim3(strips, n_caches), dim3(256), 0, s, reinterpret_cast<char*>(base), cache_stride, plane_off, row_bytes,
+                       strips, ctx, from_row);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int launch_split3(const float* in, size_t rows, int K, bf16_t* out, hipStream_t s) {
     if (rows == 0) return ZG_OK;
     ZG_REQUIRE(K % 4 == 0, ZG_ERR_UNSUPPORTED, "split3: K=%d must be a multiple of 4", K);

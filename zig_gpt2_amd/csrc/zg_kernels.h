@@ -157,6 +157,10 @@ int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 // fp32 [rows][K] -> bf16 [rows][3K] = [hi | mid | lo], hi + mid + lo == x exactly
 int launch_split3(const float* in, size_t rows, int K, bf16_t* out, hipStream_t s);
+// rows [from_row, ctx) of every (cache, sequence x head) strip set to zero: n_caches caches cache_stride bytes apart, each holding a
+// plane of [strips][ctx] rows of row_bytes at plane_off (api_gpt.hip clear_kv: what a new sequence must not inherit)
+int launch_kv_clear_tail(void* base, int n_caches, size_t cache_stride, size_t plane_off, int row_bytes, int strips, int ctx, int from_row,
+                         hipStream_t s);
 
 // ------------------------------------------------------------------------------------ MFMA GEMM
 // C[M,N] = A[M,K] * B[N,K]^T (+ bias) (optional GELU); bf16 operands, fp32 accumulate; C bf16 or fp32.
