@@ -235,7 +235,10 @@ int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* k
 
 /* GPT.forward — src/main.zig:178-195, for all `batch` sequences at once: tokens[b] is fed at
  * position seq_len-1.  If logits_out != NULL (host or device, [batch, vocab]) it receives
- * state.logits and the call is synchronous; compute_logits == 0 skips lm_head (main.zig:192). */
+ * state.logits and the call is synchronous; compute_logits == 0 skips lm_head (main.zig:192).
+ * seq_len == 1 starts a new sequence: the KV caches are cleared first (so are they by zg_gpt_prefill and zg_gpt_generate_*) —
+ * the reference's State is zero-initialised once and never reads a row it has not written; here the decode attention reads
+ * the rows of its whole 64-position bucket with weight 0, and a NaN left behind by an earlier sequence must not survive. */
 int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens,
                    int compute_logits, float* logits_out, size_t logits_len);
 /* The prompt loop of generate (src/main.zig:331-334: gpt.forward(i + 1, prompt[i], ...) for every prompt
@@ -249,7 +252,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
 int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t n_tokens,
                    int compute_logits, float* logits_out, size_t logits_len);
 /* argmax of the logits of the last zg_gpt_forward(compute_logits=1) per sequence (lowest index
- * wins ties) — the greedy replacement for GPT.sample (src/main.zig:198-207). */
+ * wins ties; logits that are all NaN give index 0) — the greedy replacement for GPT.sample (src/main.zig:198-207). */
 int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens);
 /* GPT.sample — src/main.zig:198-207 for all sequences: zg_gpt_forward(seq_len, tokens, logits), then
  * logits /= temp, softmax, and an index drawn with probability proportional to the result
