@@ -13,6 +13,8 @@ seed, count = (int(v) for v in (sys.argv[1:3] + ["0", "400"][len(sys.argv) - 1:]
 rng = np.random.default_rng(seed)
 buf = [np.zeros(1 << 21, np.float32) for _ in range(8)]  # (large enough for every weight shape below: lengths the ABI cannot check must not lie)
 idx = np.zeros(64, np.uint64)
+import torch
+dbuf = [torch.zeros(1 << 21, dtype=torch.float32, device="cuda") for _ in range(5)]
 P = lambda a: a.ctypes.data
 def size():
     return int(rng.choice([0, 0, 1, 2, 3, 7, 8, 63, 64, 65, 100, 128, 192, 255, 256, 1000, 4096, int(rng.integers(0, 1 << 16))]))
@@ -21,7 +23,7 @@ def ptr(i):
 codes = {}
 only = int(os.environ.get("ONLY", "-1"))
 for it in range(count):
-    k = int(rng.integers(0, 9))
+    k = int(rng.integers(0, 12))
     if only >= 0: k = only
     if os.environ.get("TRACE"): print("call", it, "kind", k, flush=True)
     if k == 0:
@@ -39,6 +41,22 @@ for it in range(count):
     elif k == 5: r = zg.zg_transpose(int(rng.choice([0, 1, 5])), int(rng.choice([0, 1, 12])), int(rng.choice([0, 1, 64])), ptr(0), size(), ptr(1), size())
     elif k == 6: r = zg.zg_scaled_dot_product_attention(ptr(0), size(), ptr(1), size(), ptr(2), size(), int(rng.choice([0, 1, 12])), int(rng.choice([0, 1, 7])),
                                                          int(rng.choice([0, 32, 64])), ptr(3), size(), ptr(4), size())
+    elif k == 9:   # matrix-core GEMM entry: device pointers required, K a multiple of 64 >= 128, N % 8 for bf16 out
+        dp = lambda i: None if rng.integers(0, 10) == 0 else (dbuf[i].data_ptr() if rng.integers(0, 8) else P(buf[i]))
+        M, N, K = int(rng.choice([0, 1, 17, 256, 300])), int(rng.choice([0, 1, 8, 12, 64, 200])), int(rng.choice([0, 64, 100, 128, 192, 1000]))
+        r = zg.zg_gemm_bf16_nt(dp(0), dp(1), dp(2) if rng.integers(0, 2) else None, dp(3), M, N, K, int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+    elif k == 10:  # one whole-prompt Linear (debug entry)
+        dp = lambda i: None if rng.integers(0, 10) == 0 else dbuf[i].data_ptr()
+        M, N, K = int(rng.choice([0, 1, 100, 300])), int(rng.choice([0, 32, 64, 192, 200])), int(rng.choice([0, 64, 100, 128, 256]))
+        r = zg.zg_debug_prefill_linear(dp(0), dp(1), dp(2), dp(3), M, N, K, int(rng.integers(-1, 4)), int(rng.integers(-1, 4)), int(rng.integers(0, 6)),
+                                       dp(4) if rng.integers(0, 3) else None, int(rng.choice([0, 1000, 1 << 20])))
+    elif k == 11:  # the prompt attention alone (debug entry)
+        dp = lambda i: None if rng.integers(0, 10) == 0 else dbuf[i].data_ptr()
+        B, Pn, H = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 33, 200])), int(rng.choice([0, 1, 2, 3]))
+        E = int(rng.choice([64 * H, 64 * H + 64, 100]))
+        cache = bool(rng.integers(0, 2))
+        r = zg.zg_debug_attn_prefill(dp(0), dp(1), B, Pn, E, H, dp(2) if cache else None, dp(3) if cache else None, int(rng.choice([0, Pn, 256])),
+                                     dp(4) if rng.integers(0, 3) else None, int(rng.choice([0, 100, 1 << 20])), int(rng.choice([0, 1, 3, 300, -1])))
     elif k == 7: r = zg.zg_gelu(ptr(0), size())
     else: r = zg.zg_softmax(ptr(0), size())
     codes[r] = codes.get(r, 0) + 1

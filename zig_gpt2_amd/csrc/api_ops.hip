@@ -436,7 +436,9 @@ int zg_debug_prefill_linear(const uint16_t* A, const uint16_t* W, const float* b
     ZG_TRY(require_init());
     ZG_REQUIRE(A && W && C && is_device_ptr(A) && is_device_ptr(W) && is_device_ptr(C) && (!bias || is_device_ptr(bias)) && (!ws || is_device_ptr(ws)),
                ZG_ERR_ARG, "debug_prefill_linear: device pointers");
-    ZG_REQUIRE(M < (1u << 30) && N < (1u << 30) && K < (1u << 30) && epilogue >= 0 && epilogue <= 2, ZG_ERR_ARG, "debug_prefill_linear: arguments");
+    ZG_REQUIRE(M >= 1 && M < (1u << 30) && N >= 64 && N < (1u << 30) && K >= 64 && K < (1u << 30) && epilogue >= 0 && epilogue <= 2 && force_kernel >= 0 &&
+                   force_kernel <= 2 && slices >= 0,
+               ZG_ERR_ARG, "debug_prefill_linear: arguments");
     const int epi = epilogue == 0 ? PF_F32 : epilogue == 1 ? PF_RESID : PF_GELU_SPLIT;
     prefill_force_route(force_kernel, slices);
     const int st = launch_prefill_gemm(A, W, bias, C, (int)M, (int)N, (int)K, epi == PF_GELU_SPLIT ? 0 : (int)N, epi, ws, ws_floats, nullptr, ctx().stream);

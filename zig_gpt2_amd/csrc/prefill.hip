@@ -690,7 +690,7 @@ static int s4_route(int M, int N, int K, int epi, size_t ws_floats, bool have_ws
 
 int launch_prefill_gemm(const bf16_t* A, const bf16_t* B, const float* bias, void* C, int M, int N, int K, int ldc, int epi,
                         float* ws, size_t ws_floats, const PrefillLn* ln, hipStream_t s, const PrefillQkv* qkv, int nsplit) {
-    ZG_REQUIRE(M > 0 && N % 64 == 0 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
+    ZG_REQUIRE(M > 0 && N >= 64 && N % 64 == 0 && K >= 64 && K % 64 == 0, ZG_ERR_UNSUPPORTED, "prefill gemm: M=%d N=%d K=%d", M, N, K);
     {
         const int n_sl = s4_route(M, N, K, epi, ws_floats, ws != nullptr);
         if (n_sl > 0 && epi == PF_RESID && ldc == N) {
