@@ -14,6 +14,8 @@
 // per GPU (rank r on device r); rank 0 loads the weights and ONE RCCL broadcast of the weight arena carries them to the
 // others (zg_gpt_broadcast_weights); every rank generates its prompts in lock step; one line per prompt, in prompt order.
 // --plan prints the partition and exits without touching a GPU.
+#include <poll.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -350,20 +352,64 @@ static int main_multi_gpu(int world, bool plan_only, const GPTConfig& c, const s
             close(idp[r][1]);
         }
     }
-    int failed = 0;
+    // Collect every rank's token rows as they arrive (poll: a rank's rows may exceed a pipe buffer) while watching for a rank that
+    // ends badly — no such device, unreadable weights ...: the others would wait for it in the communicator's rendezvous or in the
+    // broadcast for ever, so they are ended here, by their pids, and the run fails.
+    std::vector<std::vector<char>> got(world);
+    std::vector<size_t> want(world);
+    std::vector<bool> exited(world, false), open_fd(world, true);
     for (int r = 0; r < world; ++r) {
         size_t begin, count;
         shard_prompts(prompts.size(), world, r, begin, count);
-        std::vector<size_t> rows(count * n_steps);
-        const bool ok = rows.empty() || read_all(outp[r][0], rows.data(), rows.size() * sizeof(size_t));
-        int status = 0;
-        waitpid(pids[r], &status, 0);
-        if (!ok || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
-            ++failed;
-            continue;
+        want[r] = count * n_steps * sizeof(size_t);
+    }
+    int failed = 0, live = world;
+    while (live > 0 && failed == 0) {
+        std::vector<pollfd> fds;
+        std::vector<int> who;
+        for (int r = 0; r < world; ++r)
+            if (open_fd[r]) {
+                fds.push_back(pollfd{outp[r][0], POLLIN, 0});
+                who.push_back(r);
+            }
+        if (!fds.empty()) poll(fds.data(), fds.size(), 100);
+        for (size_t i = 0; i < fds.size(); ++i)
+            if (fds[i].revents & (POLLIN | POLLHUP)) {
+                char buf[65536];
+                const ssize_t n = read(fds[i].fd, buf, sizeof buf);
+                if (n > 0) got[who[i]].insert(got[who[i]].end(), buf, buf + n);
+                else open_fd[who[i]] = false;
+            }
+        for (int r = 0; r < world; ++r) {
+            if (exited[r]) continue;
+            int status = 0;
+            if (waitpid(pids[r], &status, WNOHANG) == pids[r]) {
+                exited[r] = true;
+                --live;
+                if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) ++failed;
+            }
         }
-        for (size_t i = 0; i < count; ++i)
-            for (size_t s = 0; s < n_steps; ++s) printf("%zu%s", rows[i * n_steps + s], s + 1 < n_steps ? " " : "\n");
+    }
+    if (failed) {
+        for (int r = 0; r < world; ++r)
+            if (!exited[r]) {
+                kill(pids[r], SIGKILL);
+                waitpid(pids[r], nullptr, 0);
+            }
+        fprintf(stderr, "a rank failed: the run is abandoned\n");
+        return 1;
+    }
+    for (int r = 0; r < world; ++r) {  // (every rank has exited: drain what is left in its pipe)
+        char buf[65536];
+        ssize_t n;
+        while (open_fd[r] && (n = read(outp[r][0], buf, sizeof buf)) > 0) got[r].insert(got[r].end(), buf, buf + n);
+        if (got[r].size() != want[r]) {
+            fprintf(stderr, "rank %d returned %zu of %zu bytes\n", r, got[r].size(), want[r]);
+            return 1;
+        }
+        const size_t* rows = reinterpret_cast<const size_t*>(got[r].data());
+        for (size_t i = 0; i < want[r] / sizeof(size_t) / (n_steps ? n_steps : 1) && n_steps; ++i)
+            for (size_t st = 0; st < n_steps; ++st) printf("%zu%s", rows[i * n_steps + st], st + 1 < n_steps ? " " : "\n");
     }
     return failed ? 1 : 0;
 }
@@ -379,17 +425,47 @@ int main(int argc, char** argv) {
     else if (name == "tiny3") config = {131, 48, 3, 3, 192};
     else if (name == "nano-char") config = {65, 256, 6, 6, 384};
     else if (name == "124M") config = {50257, 1024, 12, 12, 768};  // main.zig:346
-    else return 2;
+    else {
+        fprintf(stderr, "unknown model '%s' (tiny | tiny3 | nano-char | 124M)\n", name.c_str());
+        return 2;
+    }
     const std::string wsrc = argv[2];  // digits: seed of the synthetic weights; anything else: a raw weight directory
     const bool from_dir = wsrc.find_first_not_of("0123456789") != std::string::npos;
     const uint64_t seed = from_dir ? 0 : strtoull(argv[2], nullptr, 10);
-    const size_t n_steps = strtoull(argv[4], nullptr, 10);
-    int gpus = 0;
-    bool plan_only = false;
-    for (int i = 5; i < argc; ++i) {
-        if (std::string(argv[i]) == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
-        else if (std::string(argv[i]) == "--plan") plan_only = true;
+    auto number = [](const char* s, size_t* out) {  // a non-empty string of digits
+        if (*s == '\0' || std::string(s).find_first_not_of("0123456789") != std::string::npos) return false;
+        *out = strtoull(s, nullptr, 10);
+        return true;
+    };
+    size_t n_steps = 0;
+    if (!number(argv[4], &n_steps) || n_steps > config.context_size) {
+        fprintf(stderr, "n_steps '%s': a number of decode steps up to the context size %zu\n", argv[4], config.context_size);
+        return 2;
     }
+    int gpus = 0;
+    bool plan_only = false, model_tier = false;
+    for (int i = 5; i < argc; ++i) {
+        size_t v = 0;
+        if (std::string(argv[i]) == "--gpus" && i + 1 < argc && number(argv[i + 1], &v) && v >= 1 && v <= 64) gpus = (int)v, ++i;
+        else if (std::string(argv[i]) == "--plan") plan_only = true;
+        else if (std::string(argv[i]) == "--model-tier") model_tier = true;
+        else {
+            fprintf(stderr, "unknown or incomplete option '%s' (--model-tier | --gpus N [--plan], N = 1..64)\n", argv[i]);
+            return 2;
+        }
+    }
+    auto tokens_of = [&](std::string item, std::vector<size_t>* out) {  // "tok,tok,...": ids below the vocabulary size
+        for (char* p = strtok(item.data(), ","); p; p = strtok(nullptr, ",")) {
+            size_t t = 0;
+            if (!number(p, &t) || t >= config.vocab_size) {
+                fprintf(stderr, "token '%s': ids are numbers below the vocabulary size %zu\n", p, config.vocab_size);
+                return false;
+            }
+            out->push_back(t);
+        }
+        if (out->empty()) fprintf(stderr, "empty prompt\n");
+        return !out->empty();
+    };
     if (gpus > 0) {
         std::vector<std::vector<size_t>> prompts;
         std::string all = argv[3];
@@ -397,20 +473,14 @@ int main(int argc, char** argv) {
         while (pos <= all.size()) {
             const size_t end = std::min(all.find(';', pos), all.size());
             std::vector<size_t> one;
-            std::string item = all.substr(pos, end - pos);
-            for (char* p = strtok(item.data(), ","); p; p = strtok(nullptr, ",")) one.push_back(strtoull(p, nullptr, 10));
-            if (one.empty()) {
-                fprintf(stderr, "empty prompt\n");
-                return 2;
-            }
+            if (!tokens_of(all.substr(pos, end - pos), &one)) return 2;
             prompts.push_back(one);
             pos = end + 1;
         }
         return main_multi_gpu(gpus, plan_only, config, wsrc, from_dir, seed, prompts, n_steps);
     }
     std::vector<size_t> inputs;
-    for (char* p = strtok(argv[3], ","); p; p = strtok(nullptr, ",")) inputs.push_back(strtoull(p, nullptr, 10));
-    const bool model_tier = argc > 5 && std::string(argv[5]) == "--model-tier";
+    if (!tokens_of(argv[3], &inputs)) return 2;
     try {
         ops::check(zg_init(0));
         const Weights w = from_dir ? Weights(config, wsrc) : Weights(config, seed);
