@@ -108,7 +108,8 @@ int zg_transpose(size_t seq_len, size_t n_heads, size_t head_dim, const float* i
                  size_t inputs_len, float* outputs, size_t outputs_len);
 
 /* scaled_dot_product_attention — src/ops.zig:249-307.  q [B,H,1,hd], k/v [B,H,T,hd],
- * outputs [B,H,1,hd]; B = k_len / (H*T*hd) (ops.zig:259); _attn_len must be >= seq_len. */
+ * outputs [B,H,1,hd]; B = k_len / (H*T*hd) (ops.zig:259); _attn_len must be >= seq_len.  Any head_dim up to 2048: 64 (every
+ * GPT-2 configuration) runs the split-KV kernels, anything else a general fp32 kernel (one workgroup per sequence and head). */
 int zg_scaled_dot_product_attention(const float* q, size_t q_len, const float* k, size_t k_len,
                                     const float* v, size_t v_len, size_t n_heads, size_t seq_len,
                                     size_t head_dim, float* outputs, size_t outputs_len,

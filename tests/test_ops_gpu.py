@@ -300,7 +300,7 @@ def test_error_behaviour(zg):
     with pytest.raises(_lib.ZgError):
         ops.Embedding(8, z(4, 8)).forward(np.array([5], np.uint64), z(8))  # index out of range
     with pytest.raises(_lib.ZgError):
-        ops.scaled_dot_product_attention(z(32), z(32), z(32), 1, 1, 32, z(32), z(1))  # head_dim != 64
+        ops.scaled_dot_product_attention(z(4096), z(4096), z(4096), 1, 1, 4096, z(4096), z(1))  # head_dim beyond the general kernel's 2048
 
 
 def test_null_slices_are_refused_not_dereferenced(zg):
@@ -316,3 +316,30 @@ def test_null_slices_are_refused_not_dereferenced(zg):
     assert zg.zg_transpose(1, 1, 8, None, 8, x.ctypes.data, 8) == ERR_ARG
     assert zg.zg_transpose(1, 1, 8, x.ctypes.data, 8, None, 8) == ERR_ARG
     assert zg.zg_linear_forward(8, 4, w.ctypes.data, None, x.ctypes.data, 8, x.ctypes.data, 4) == 0  # (and the library carries on)
+
+
+@pytest.mark.parametrize("hds,hd,T", [(3, 32, 70), (2, 48, 300), (5, 80, 33), (1, 128, 513), (4, 7, 19), (2, 300, 40)])
+def test_attention_with_a_head_dimension_other_than_64(zg, hds, hd, T):
+    """src/ops.zig:249-307 takes any head_dim; the GPT-2 family has 64 (the fast kernels), everything else runs the op tier's
+    general attention kernel: scaled_dot_product_attention on head-major q / k / v and CausalSelfAttention.forward over an
+    incremental cache, both against the oracle."""
+    q = synth.fill_normal(401, hds * hd, 0, 1.0)
+    k = synth.fill_normal(402, hds * T * hd, 0, 1.0)
+    v = synth.fill_normal(403, hds * T * hd, 0, 1.0)
+    out = z(hds * hd)
+    ops.scaled_dot_product_attention(q, k, v, hds, T, hd, out, z(T))
+    assert_ref_close(oracle.sdpa(q, k, v, hds, T, hd), out, f"sdpa heads {hds} head_dim {hd} T {T}", scale_floor=2e-6)
+    e, steps = hds * hd, min(T, 40)
+    caw = synth.fill_normal(404, 3 * e * e, 0, 0.04).reshape(3 * e, e)
+    cab = synth.fill_normal(405, 3 * e, 0, 0.05)
+    cpw = synth.fill_normal(406, e * e, 0, 0.04).reshape(e, e)
+    cpb = synth.fill_normal(407, e, 0, 0.05)
+    xs = synth.fill_normal(408, steps * e, 0, 1.0).reshape(steps, e)
+    ref = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, steps)
+    attn = ops.CausalSelfAttention(hds, e, ops.Linear(e, 3 * e, caw, cab), ops.Linear(e, e, cpw, cpb))
+    k_cache, v_cache = z(steps * e), z(steps * e)
+    _qkv, _q, _k, _v, _attn = z(3 * e), z(e), z(steps * e), z(steps * e), z(steps)
+    for s_ in range(steps):
+        o = z(e)
+        attn.forward(s_ + 1, xs[s_], k_cache[: (s_ + 1) * e], v_cache[: (s_ + 1) * e], o, _qkv, _q, _k[: (s_ + 1) * e], _v[: (s_ + 1) * e], _attn[: s_ + 1])
+        assert_ref_close(ref.forward(s_ + 1, xs[s_]), o, f"attn head_dim {hd} step {s_}", scale_floor=2e-6)

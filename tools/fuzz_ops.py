@@ -71,7 +71,7 @@ for seed in range(first, first + count):
             what = f"gelu n {n}"
             assert np.abs(x - ref).max() < 2e-6, what
         elif kind == 6:  # CausalSelfAttention.forward over T incremental steps against the oracle's
-            hds = int(rng.integers(1, 7)); e = 64 * hds; T = int(rng.integers(1, 330))
+            hds = int(rng.integers(1, 7)); hd = 64 if rng.integers(0, 2) else int(rng.choice([8, 24, 32, 40, 96, 128])); e = hd * hds; T = int(rng.integers(1, 330))
             caw = synth.fill_normal(seed + 10, 3 * e * e, 0, 0.08).reshape(3 * e, e); cab = synth.fill_normal(seed + 11, 3 * e, 0, 0.05)
             cpw = synth.fill_normal(seed + 12, e * e, 0, 0.08).reshape(e, e); cpb = synth.fill_normal(seed + 13, e, 0, 0.05)
             xs = synth.fill_normal(seed + 14, T * e, 0, 1.0).reshape(T, e)
@@ -80,7 +80,7 @@ for seed in range(first, first + count):
             z = lambda *sh: np.zeros(sh, np.float32)
             k_cache, v_cache = z(T * e), z(T * e)
             _qkv, _q, _k, _v, _attn = z(3 * e), z(e), z(T * e), z(T * e), z(T)
-            what = f"attn heads {hds} T {T}"
+            what = f"attn heads {hds} head_dim {hd} T {T}"
             for st in range(T):
                 out = z(e)
                 attn.forward(st + 1, xs[st], k_cache[: (st + 1) * e], v_cache[: (st + 1) * e], out, _qkv, _q, _k[: (st + 1) * e], _v[: (st + 1) * e], _attn[: st + 1])
@@ -88,12 +88,12 @@ for seed in range(first, first + count):
                 assert np.abs(out - exp).max() <= 2e-5 * max(1.0, np.abs(exp).max()), (what, st)
             assert np.abs(k_cache - ref.k_cache).max() < 1e-5 and np.abs(v_cache - ref.v_cache).max() < 1e-5, what
         elif kind == 7:  # scaled_dot_product_attention on head-major q / k / v
-            hds = int(rng.integers(1, 13)); T = int(rng.integers(1, 700))
-            q = synth.fill_normal(seed + 15, hds * 64, 0, 1.0); k = synth.fill_normal(seed + 16, hds * T * 64, 0, 1.0); v = synth.fill_normal(seed + 17, hds * T * 64, 0, 1.0)
-            out, _attn = np.zeros(hds * 64, np.float32), np.zeros(T, np.float32)
-            ops.scaled_dot_product_attention(q, k, v, hds, T, 64, out, _attn)
-            exp = oracle.sdpa(q, k, v, hds, T, 64)
-            what = f"sdpa heads {hds} T {T}"
+            hds = int(rng.integers(1, 13)); T = int(rng.integers(1, 700)); hd = 64 if rng.integers(0, 2) else int(rng.integers(1, 200))
+            q = synth.fill_normal(seed + 15, hds * hd, 0, 1.0); k = synth.fill_normal(seed + 16, hds * T * hd, 0, 1.0); v = synth.fill_normal(seed + 17, hds * T * hd, 0, 1.0)
+            out, _attn = np.zeros(hds * hd, np.float32), np.zeros(T, np.float32)
+            ops.scaled_dot_product_attention(q, k, v, hds, T, hd, out, _attn)
+            exp = oracle.sdpa(q, k, v, hds, T, hd)
+            what = f"sdpa heads {hds} T {T} head_dim {hd}"
             assert np.abs(out - exp).max() <= 5e-6 * max(1.0, np.abs(exp).max()), what
         elif kind == 8:  # split_qkv + transpose
             hds = int(rng.integers(1, 13)); e = 64 * hds; T = int(rng.integers(1, 200)); idx = int(rng.integers(0, 3))

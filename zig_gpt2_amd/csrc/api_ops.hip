@@ -253,7 +253,9 @@ static int linear_device_wide(Call& call, size_t in_f, size_t out_f, const float
 }
 
 static int attn_core(const float* q, const float* k, const float* v, long stride_b, long stride_h,
-                     long stride_t, size_t batch, size_t n_heads, size_t seq_len, float* out, hipStream_t s) {
+                     long stride_t, size_t batch, size_t n_heads, size_t seq_len, float* out, hipStream_t s, size_t head_dim = 64) {
+    if (head_dim != 64)
+        return launch_attn_any_dim(q, k, v, stride_b, stride_h, stride_t, (int)batch, (int)n_heads, (int)head_dim, (int)seq_len, out, s);
     Ctx& c = ctx();
     const int splits = (int)((seq_len + kAttnChunk - 1) / kAttnChunk);
     ZG_REQUIRE(batch * n_heads * splits * kPartStride <= c.attn_part_floats, ZG_ERR_UNSUPPORTED,
@@ -606,8 +608,9 @@ int zg_scaled_dot_product_attention(const float* q, size_t q_len, const float* k
     ZG_TRY(require_init());
     (void)_attn;
     ZG_REQUIRE(n_heads > 0 && seq_len > 0 && head_dim > 0, ZG_ERR_ARG, "sdpa: empty shape");
-    ZG_REQUIRE(head_dim == 64, ZG_ERR_UNSUPPORTED, "sdpa: head_dim %zu != 64 (GPT-2 family only)", head_dim);
+    ZG_REQUIRE(head_dim <= 2048, ZG_ERR_UNSUPPORTED, "sdpa: head_dim %zu beyond 2048", head_dim);
     const size_t batch = k_len / (n_heads * seq_len * head_dim);  // ops.zig:259
+    ZG_REQUIRE(batch == 0 || (q && k && v && outputs), ZG_ERR_ARG, "sdpa: null argument");
     ZG_REQUIRE(v_len >= k_len && q_len >= batch * n_heads * head_dim && outputs_len >= batch * n_heads * head_dim &&
                    _attn_len >= seq_len,
                ZG_ERR_SHAPE, "sdpa: slice lengths inconsistent with batch %zu", batch);
@@ -620,7 +623,7 @@ int zg_scaled_dot_product_attention(const float* q, size_t q_len, const float* k
     ZG_TRY(call.in(v, k_len, &dv));
     ZG_TRY(call.out(outputs, batch * n_heads * head_dim, &out));
     ZG_TRY(attn_core(dq, dk, dv, (long)(n_heads * seq_len * head_dim), (long)(seq_len * head_dim), (long)head_dim,
-                     batch, n_heads, seq_len, out, call.stream()));
+                     batch, n_heads, seq_len, out, call.stream(), head_dim));
     ZG_TRY(call.finish());
     guard.done = true;
     return ZG_OK;
@@ -639,14 +642,17 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     (void)_attn;
     const size_t E = n_embed;
     ZG_REQUIRE(n_heads > 0 && E > 0 && seq_len > 0, ZG_ERR_ARG, "attn: empty shape");
-    ZG_REQUIRE(E % n_heads == 0 && E / n_heads == 64, ZG_ERR_UNSUPPORTED,
-               "attn: head_dim %zu != 64 (GPT-2 family only)", E / n_heads);
+    ZG_REQUIRE(E % n_heads == 0, ZG_ERR_SHAPE, "attn: n_embed %zu is not a multiple of n_heads %zu", E, n_heads);
+    const size_t hd = E / n_heads;  // 64 for every GPT-2 configuration; anything else takes the op tier's general attention kernel
     ZG_REQUIRE(inputs_len == E, ZG_ERR_SHAPE, "attn: batch must be 1 (inputs.len %zu != n_embed %zu; ops.zig:126-128)",
                inputs_len, E);
     ZG_REQUIRE(k_cache_len >= seq_len * E && v_cache_len >= seq_len * E && outputs_len >= E &&
                    _qkv_len >= 3 * E && _q_len >= E && _k_len >= seq_len * E && _v_len >= seq_len * E &&
                    _attn_len >= seq_len,
                ZG_ERR_SHAPE, "attn: a slice is shorter than seq_len %zu * n_embed %zu requires", seq_len, E);
+    ZG_REQUIRE(c_attn_weight && c_attn_bias && c_proj_weight && c_proj_bias && inputs && k_cache && v_cache && outputs && _qkv && _q, ZG_ERR_ARG,
+               "attn: null argument");
+    ZG_REQUIRE(hd <= 2048, ZG_ERR_UNSUPPORTED, "attn: head_dim %zu beyond 2048", hd);
     Call call;
     CallGuard guard(call);
     hipStream_t s = call.stream();
@@ -673,7 +679,7 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     ZG_TRY(launch_copy_f32(qkv + 2 * E, vc + (seq_len - 1) * E, E, s));
     // attention straight over the [T, H, hd] cache (replaces transposes + sdpa, ops.zig:153-171);
     // the merged heads land in _q like the reference's "untranspose" (ops.zig:171)
-    ZG_TRY(attn_core(qkv, kc, vc, 0, 64, (long)E, 1, n_heads, seq_len, q, s));
+    ZG_TRY(attn_core(qkv, kc, vc, 0, (long)hd, (long)E, 1, n_heads, seq_len, q, s, hd));
     // c_proj (ops.zig:172)
     ZG_TRY(linear_device(E, E, cpw, cpb, q, 1, out, s));
     ZG_TRY(call.finish());

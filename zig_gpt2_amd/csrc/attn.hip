@@ -567,6 +567,87 @@ int launch_attn_decode(const AttnArgs& a, hipStream_t s) {
     return ZG_OK;
 }
 
+// scaled_dot_product_attention for a head dimension other than 64 (src/ops.zig:249-307 takes any; every GPT-2 configuration has
+// 64 and runs the kernels above).  The op tier's general path, not a fast one: one workgroup per (sequence, head); pass 1 finds
+// the row maximum of alpha q . k_t, pass 2 goes over the positions 256 at a time — every thread the probability of one position
+// into LDS, then thread d the weighted sum of v[., d] over the chunk.  fp32 throughout, alpha = 1 / sqrt(head_dim) applied to the
+// dot product like sgemm's alpha (ops.zig:275).
+__global__ __launch_bounds__(256) void attn_any_dim_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           long stride_b, long stride_h, long stride_t, int n_heads, int head_dim, int T,
+                                                           float* __restrict__ out) {
+    __shared__ float s_p[256];
+    __shared__ float s_red[8];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* qh = q + ((size_t)b * n_heads + h) * head_dim;
+    const float* kh = k + (size_t)b * stride_b + (size_t)h * stride_h;
+    const float* vh = v + (size_t)b * stride_b + (size_t)h * stride_h;
+    const float alpha = 1.0f / sqrtf((float)head_dim);
+    auto score = [&](int t) {
+        const float* kt = kh + (size_t)t * stride_t;
+        float acc = 0.0f;
+        for (int d = 0; d < head_dim; ++d) acc = fmaf(qh[d], kt[d], acc);
+        return acc * alpha;
+    };
+    auto block_max = [&](float x) {
+        x = wave_allmax(x);
+        if ((tid & 63) == 0) s_red[tid >> 6] = x;
+        __syncthreads();
+        const float r = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        __syncthreads();
+        return r;
+    };
+    auto block_sum = [&](float x) {
+        x = wave_allsum(x);
+        if ((tid & 63) == 0) s_red[tid >> 6] = x;
+        __syncthreads();
+        const float r = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        __syncthreads();
+        return r;
+    };
+    float mx = -3.0e38f;
+    for (int t = tid; t < T; t += 256) mx = fmaxf(mx, score(t));
+    mx = block_max(mx);
+    // output dimensions d = tid, tid + 256, ... (at most 8 per thread: head_dim <= 2048, checked by the launcher)
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+    float l = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int t = t0 + tid;
+        const float p = t < T ? __expf(score(t) - mx) : 0.0f;
+        s_p[tid] = p;
+        l += p;
+        __syncthreads();
+        const int n = min(256, T - t0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = tid + 256 * j;
+            if (d < head_dim) {
+                float acc = o[j];
+                for (int i = 0; i < n; ++i) acc = fmaf(s_p[i], vh[(size_t)(t0 + i) * stride_t + d], acc);
+                o[j] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    l = block_sum(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = tid + 256 * j;
+        if (d < head_dim) out[((size_t)b * n_heads + h) * head_dim + d] = o[j] * inv;
+    }
+}
+
+int launch_attn_any_dim(const float* q, const float* k, const float* v, long stride_b, long stride_h, long stride_t, int batch, int n_heads,
+                        int head_dim, int seq_len, float* out, hipStream_t s) {
+    ZG_REQUIRE(head_dim >= 1 && head_dim <= 2048 && n_heads >= 1 && n_heads < 65536 && batch >= 1 && batch < 65536 && seq_len >= 1, ZG_ERR_UNSUPPORTED,
+               "attention: head_dim %d / heads %d / batch %d", head_dim, n_heads, batch);
+    hipLaunchKernelGGL(attn_any_dim_kernel, dim3(n_heads, batch), dim3(256), 0, s, q, k, v, stride_b, stride_h, stride_t, n_heads, head_dim, seq_len, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, int max_splits,
                       int seq_len, float* out, hipStream_t s) {
     ZG_REQUIRE(head_dim == 64, ZG_ERR_UNSUPPORTED, "attention: head_dim %d != 64", head_dim);

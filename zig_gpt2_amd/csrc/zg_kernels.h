@@ -140,6 +140,9 @@ struct AttnArgs {
     unsigned spin_limit;
 };
 int launch_attn_decode(const AttnArgs& a, hipStream_t s);
+// the op tier's general path for head_dim != 64 (fp32, one workgroup per (sequence, head))
+int launch_attn_any_dim(const float* q, const float* k, const float* v, long stride_b, long stride_h, long stride_t, int batch, int n_heads,
+                        int head_dim, int seq_len, float* out, hipStream_t s);
 // Standalone merge (op tier): out[b][h*hd+d] = sum_s w_s o_s / sum_s w_s l_s
 int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, int max_splits,
                       int seq_len, float* out, hipStream_t s);
