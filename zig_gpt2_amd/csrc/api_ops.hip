@@ -254,12 +254,11 @@ static int linear_device_wide(Call& call, size_t in_f, size_t out_f, const float
 
 static int attn_core(const float* q, const float* k, const float* v, long stride_b, long stride_h,
                      long stride_t, size_t batch, size_t n_heads, size_t seq_len, float* out, hipStream_t s, size_t head_dim = 64) {
-    if (head_dim != 64)
-        return launch_attn_any_dim(q, k, v, stride_b, stride_h, stride_t, (int)batch, (int)n_heads, (int)head_dim, (int)seq_len, out, s);
     Ctx& c = ctx();
     const int splits = (int)((seq_len + kAttnChunk - 1) / kAttnChunk);
-    ZG_REQUIRE(batch * n_heads * splits * kPartStride <= c.attn_part_floats, ZG_ERR_UNSUPPORTED,
-               "attention: batch*heads*splits = %zu exceeds the op-tier partial buffer", batch * n_heads * splits);
+    // (a shape whose split partials do not fit the op tier's buffer — very long sequences x many heads — takes the general kernel too)
+    if (head_dim != 64 || batch * n_heads * splits * kPartStride > c.attn_part_floats)
+        return launch_attn_any_dim(q, k, v, stride_b, stride_h, stride_t, (int)batch, (int)n_heads, (int)head_dim, (int)seq_len, out, s);
     AttnArgs a{};
     a.q = q;
     a.k = k;
