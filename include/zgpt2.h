@@ -208,6 +208,21 @@ enum { ZG_WTE = 0, ZG_WPE, ZG_LN_F_G, ZG_LN_F_B, ZG_N_TOP_SLOTS };
  * decoded in lock step (the reference supports 1, src/ops.zig:126-128). */
 int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsigned flags);
 int zg_gpt_destroy(zg_gpt* g);
+/* Independent prompt GROUPS on one GPU (no reference counterpart: the reference decodes one sequence, src/ops.zig:126-128).
+ * A decode step is a chain of dependent launches that leaves the chip idle across every launch boundary, and prompts are
+ * independent units — so instead of one handle of 8 sequences in lock step, G handles of 8/G sequences each run their chains
+ * side by side: own_stream gives a handle a private stream (stream_priority: 0 normal, > 0 high, < 0 low — streams of
+ * different priorities never share a hardware queue), share_weights_with lets it read the weight region of another handle of
+ * the same config and weight flags instead of holding a copy (that handle loads / broadcasts the weights and must be destroyed
+ * last).  zg_gpt_create(...) == zg_gpt_create_ex(..., NULL). */
+typedef struct {
+    zg_gpt* share_weights_with; /* NULL: own weight region */
+    int own_stream;             /* 0: the library stream (zg_set_stream applies); 1: a private stream made here */
+    int stream_priority;
+} zg_gpt_options;
+int zg_gpt_create_ex(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsigned flags, const zg_gpt_options* options_or_null);
+/* The hipStream_t a handle launches on (its private stream, or the library stream of the moment). */
+int zg_gpt_stream(zg_gpt* g, void** hip_stream_out);
 
 /* Weight upload (replaces load_linear/load_layer_norm/load_embedding, src/main.zig:210-269).
  * src is fp32, host or device; matrices are converted to the arena's storage type on device. */
@@ -281,6 +296,14 @@ int zg_gpt_generate_greedy(zg_gpt* g, const size_t* prompts, size_t prompt_strid
 int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride,
                             const size_t* prompt_lens, size_t n_steps);
 int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t out_len);
+/* The same for the prompts of several handles at once (handles on distinct streams: zg_gpt_create_ex): prompts is
+ * [sum of the handles' batches, prompt_stride], rows in handle order, prompt_lens alike; every handle generates its own rows,
+ * the handles' graph launches are enqueued turn by turn so that no hardware queue starves while another one is being filled.
+ * zg_gpt_generate_fetch_many drains every handle and returns out_tokens [sum of batches, n_steps] in the same row order.
+ * Token for token the result equals one handle per prompt (sequences never interact). */
+int zg_gpt_generate_enqueue_many(zg_gpt* const* handles, size_t n_handles, const size_t* prompts, size_t prompt_stride,
+                                 const size_t* prompt_lens, size_t n_steps);
+int zg_gpt_generate_fetch_many(zg_gpt* const* handles, size_t n_handles, size_t n_steps, size_t* out_tokens, size_t out_len);
 
 /* ------------------------------------------------------------------ measurement helpers ---- */
 

@@ -32,6 +32,12 @@ class GptConfig(C.Structure):
     _fields_ = [("vocab_size", sz), ("context_size", sz), ("n_layer", sz), ("n_heads", sz), ("n_embed", sz)]
 
 
+class GptOptions(C.Structure):
+    """zg_gpt_options of include/zgpt2.h."""
+
+    _fields_ = [("share_weights_with", vp), ("own_stream", C.c_int), ("stream_priority", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/zgpt2.h declares
 SIGNATURES = {
     "zg_init": (C.c_int, [C.c_int]),
@@ -62,6 +68,10 @@ SIGNATURES = {
     "zg_softmax": (C.c_int, [vp, sz]),
     "zg_gpt_create": (C.c_int, [C.POINTER(vp), C.POINTER(GptConfig), sz, C.c_uint]),
     "zg_gpt_destroy": (C.c_int, [vp]),
+    "zg_gpt_create_ex": (C.c_int, [C.POINTER(vp), C.POINTER(GptConfig), sz, C.c_uint, vp]),
+    "zg_gpt_stream": (C.c_int, [vp, C.POINTER(vp)]),
+    "zg_gpt_generate_enqueue_many": (C.c_int, [vp, sz, vp, sz, vp, sz]),
+    "zg_gpt_generate_fetch_many": (C.c_int, [vp, sz, sz, vp, sz]),
     "zg_gpt_load_block_tensor": (C.c_int, [vp, sz, C.c_int, vp, sz]),
     "zg_gpt_load_tensor": (C.c_int, [vp, C.c_int, vp, sz]),
     "zg_gpt_weight_arena": (C.c_int, [vp, C.POINTER(vp), szp]),

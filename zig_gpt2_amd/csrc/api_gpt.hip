@@ -11,9 +11,12 @@
 //                                                            contiguous [ctx, 64] slab, so no
 //                                                            per-step transpose (ops.zig:153,158)
 //   [ scratch: x q h4 attention partials logits argmax partials, control block, token buffers ]
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "zg_runtime.h"
@@ -39,7 +42,7 @@ struct zg_gpt {
     int kv_mode;
     size_t wbytes;  // bytes per matrix element
     char* arena;
-    size_t arena_bytes, weight_region_bytes;
+    size_t arena_bytes, weight_region_bytes, state_bytes;  // arena = [weight region (absent when borrowed) | state]
     size_t kv_region_bytes;  // the KV caches of all layers: one contiguous stretch of the arena from layers[0].k_cache
     void *wte, *wpe;
     float *ln_f_g, *ln_f_b;
@@ -102,7 +105,19 @@ struct zg_gpt {
     int pf_sit_out;   // generate calls left before a stalled prefetcher is tried again
     hipStream_t pf_stream;
     hipEvent_t pf_ev_main, pf_ev_side;
+    // independent prompt groups on one GPU (zg_gpt_create_ex): a private stream, so that the decode chains of several handles
+    // overlap on the chip, and a weight region borrowed from another handle of the same model
+    hipStream_t stream;  // nullptr: the library stream of the moment (zg_set_stream)
+    zg_gpt* parent;      // owner of the weight region this handle reads (nullptr: its own)
+    int n_children;      // handles borrowing this one's weight region
+    char* wbase;         // the weight region: arena, or the parent's
+    // a generation in flight between gen_begin and gen_end (zg_gpt_generate_enqueue / _many)
+    size_t gen_pos, gen_n, gen_min_prompt, gen_since_sync;
+    bool gen_open;
 };
+
+static inline hipStream_t gs(const zg_gpt* g) { return g->stream ? g->stream : ctx().stream; }
+static inline zg_gpt* root(zg_gpt* g) { return g->parent ? g->parent : g; }
 
 namespace {
 
@@ -116,12 +131,14 @@ struct Carver {
     }
 };
 
-// One pass computes sizes (base == nullptr) or assigns pointers.
-void carve(zg_gpt* g, char* base) {
+// One pass computes sizes (both bases nullptr) or assigns pointers: the weight region from wbase (the handle's own arena or the
+// one it borrows), everything else — KV caches, scratch, control — from sbase.
+void carve(zg_gpt* g, char* wbase, char* sbase) {
     const zg_gpt_config& c = g->cfg;
     const size_t E = c.n_embed, V = c.vocab_size, C = c.context_size, L = c.n_layer, B = g->batch;
     const size_t wb = g->wbytes, kvb = g->kv_mode == 1 ? 2 : g->kv_mode == 2 ? 3 : 4;  // B24: a bf16 plane, then a byte plane
     Carver cv;
+    char* base = wbase;
     auto P = [&](size_t bytes) -> char* {
         const size_t o = cv.take(bytes);
         return base ? base + o : nullptr;
@@ -160,6 +177,8 @@ void carve(zg_gpt* g, char* base) {
         }
     }
     g->weight_region_bytes = (cv.off + 255) & ~(size_t)255;
+    cv = Carver{};
+    base = sbase;
     for (size_t l = 0; l < L; ++l) {
         g->layers[l].k_cache = P(B * C * E * kvb);
         g->layers[l].v_cache = P(B * C * E * kvb);
@@ -211,7 +230,7 @@ void carve(zg_gpt* g, char* base) {
         g->pf_ws = (float*)P(g->pf_ws_floats * 4);
         g->sk_flags = (unsigned*)P(2048);
     }
-    g->arena_bytes = (cv.off + 255) & ~(size_t)255;
+    g->state_bytes = (cv.off + 255) & ~(size_t)255;
 }
 
 int bucket_t_hi(const zg_gpt* g, size_t seq_len) {
@@ -348,14 +367,17 @@ inline int prof_mark(StepProf* p, int cls, hipStream_t s) {
 // (Re)derive the folded-LayerNorm vectors from the weights in the arena: after loading, or on ranks that received
 // the weight region by broadcast.  A handful of small launches outside any graph.
 int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
-    if (g->ln_folded) return ZG_OK;
+    zg_gpt* r = root(g);  // the vectors live in the weight region: one flag per region, kept by its owner
+    if (r->ln_folded) return ZG_OK;
     const int E = (int)g->cfg.n_embed;
     for (const zg_layer& y : g->layers) {
         ZG_TRY(launch_ln_fold(y.c_attn_w, g->wt, y.ln_1_g, y.ln_1_b, y.c_attn_b, 3 * E, E, y.c_attn_c2, y.c_attn_c3, s));
         ZG_TRY(launch_ln_fold(y.c_fc_w, g->wt, y.ln_2_g, y.ln_2_b, y.c_fc_b, 4 * E, E, y.c_fc_c2, y.c_fc_c3, s));
     }
     ZG_TRY(launch_ln_fold(g->wte, g->wt, g->ln_f_g, g->ln_f_b, nullptr, (int)g->cfg.vocab_size, E, g->lm_c2, g->lm_c3, s));
-    g->ln_folded = true;
+    // handles that share the region run on other streams: the vectors must be complete before any of them reads the flag
+    if (r->n_children > 0 || g->parent) ZG_HIP(hipStreamSynchronize(s));
+    r->ln_folded = true;
     return ZG_OK;
 }
 
@@ -574,21 +596,27 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
 // call).  The word lives in pinned host memory the kernels store to directly: reading it costs no copy and no second
 // synchronisation.  PRECONDITION: the stream has been drained since the steps in question.
 int check_fault(zg_gpt* g) {
+    // both words are read and cleared before anything is reported: a tag fault left latched behind a stream-K fault of the same
+    // drain would be charged to a later, healthy call
+    unsigned sk = 0, tag = 0;
     if (g->sk_used) {  // a whole-prompt pass may have handed half tiles over inside gemm_s4: did a consumer give up waiting?
         g->sk_used = false;
-        unsigned f = 0;
-        ZG_TRY(gemm_s4_fault(&f));
-        if (f) {
-            set_error("a half-tile hand-over of the whole-prompt c_attn GEMM timed out: results discarded");
-            return ZG_ERR_HIP;
-        }
+        ZG_TRY(gemm_s4_fault(&sk));
     }
-    if (!g->tags_on) return ZG_OK;
-    volatile unsigned* f = g->fault;
-    if (*f == 0) return ZG_OK;
-    *f = 0;
-    set_error("a tagged hand-over of the decode step timed out (a workgroup waited %u polls for its writers): results discarded", g->spin_limit);
-    return ZG_ERR_HIP;
+    if (g->tags_on) {
+        volatile unsigned* f = g->fault;
+        tag = *f;
+        if (tag) *f = 0;
+    }
+    if (sk) {
+        set_error("a half-tile hand-over of the whole-prompt c_attn GEMM timed out%s: results discarded", tag ? " (and a tagged hand-over of the decode step)" : "");
+        return ZG_ERR_HIP;
+    }
+    if (tag) {
+        set_error("a tagged hand-over of the decode step timed out (a workgroup waited %u polls for its writers): results discarded", g->spin_limit);
+        return ZG_ERR_HIP;
+    }
+    return ZG_OK;
 }
 
 // A tag is (epoch << 8 | launch id) in 32 bits: 24 bits of the step counter survive, and a slot that is only written at long
@@ -621,7 +649,7 @@ int setup_prefetcher(zg_gpt* g) {
     // token; GPT-2 XL's 20 MB matrices cannot be fetched a launch ahead, 8 prompts gain < 1 %).  ZGPT2_PREFETCH=1 / 0 forces.
     const bool small = g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
     const int want = env_int("ZGPT2_PREFETCH", small ? 1 : 0);
-    if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || ctx().stream == nullptr) return ZG_OK;
+    if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || gs(g) == nullptr) return ZG_OK;
     if (g->pf_njobs > 255) return ZG_OK;  // the progress word counts launches in 8 bits (n_layer >= 51): no prefetcher, not an error
     std::vector<PfJob> jobs;
     ZG_TRY(enqueue_step(g, true, (int)g->cfg.context_size, nullptr, nullptr, -1, 0, &jobs));
@@ -807,9 +835,20 @@ int upload_f32(const float* src, size_t n, void* dst, bool as_bf16, hipStream_t 
 extern "C" {
 
 int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsigned flags) {
+    return zg_gpt_create_ex(out, config, batch, flags, nullptr);
+}
+
+int zg_gpt_create_ex(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsigned flags, const zg_gpt_options* opt) {
     ZG_TRY(require_init());
     ZG_REQUIRE(out && config, ZG_ERR_ARG, "zg_gpt_create: null argument");
     const zg_gpt_config& c = *config;
+    zg_gpt* parent = opt ? opt->share_weights_with : nullptr;
+    if (parent) {
+        ZG_REQUIRE(parent->parent == nullptr, ZG_ERR_ARG, "zg_gpt_create_ex: share_weights_with must own its weights");
+        ZG_REQUIRE(memcmp(&parent->cfg, config, sizeof(zg_gpt_config)) == 0, ZG_ERR_SHAPE, "zg_gpt_create_ex: a handle shares weights with one of the same config only");
+        const unsigned same = ZG_GPT_WEIGHTS_F32 | ZG_GPT_NO_PREFILL;  // what decides the layout of the weight region
+        ZG_REQUIRE((parent->flags & same) == (flags & same), ZG_ERR_ARG, "zg_gpt_create_ex: weight type / prefill flags differ from the weight owner's");
+    }
     ZG_REQUIRE(c.n_heads > 0 && c.n_embed % c.n_heads == 0 && c.n_embed / c.n_heads == 64, ZG_ERR_UNSUPPORTED,
                "head_dim %zu != 64 (GPT-2 family only)", c.n_heads ? c.n_embed / c.n_heads : (size_t)0);
     ZG_REQUIRE(c.n_embed % 8 == 0 && c.n_embed * 4 <= 8192, ZG_ERR_UNSUPPORTED, "n_embed %zu unsupported", c.n_embed);
@@ -825,14 +864,34 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     g->kv_mode = (flags & ZG_GPT_KV_F16) ? 1 : (flags & ZG_GPT_KV_B24) ? 2 : 0;
     g->max_splits = (int)((c.context_size + kAttnChunk - 1) / kAttnChunk);
     g->graph_stream = nullptr;
-    carve(g, nullptr);
+    g->stream = nullptr;
+    g->parent = parent;
+    g->n_children = 0;
+    g->gen_open = false;
+    g->pf_stream = nullptr;
+    g->pf_ev_main = g->pf_ev_side = nullptr;
+    carve(g, nullptr, nullptr);
+    g->arena_bytes = (parent ? 0 : g->weight_region_bytes) + g->state_bytes;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->arena), g->arena_bytes);
     if (e != hipSuccess) {
         delete g;
         return hip_fail(e, "hipMalloc(model arena)", __FILE__, __LINE__);
     }
-    carve(g, g->arena);
-    (void)hipMemset(g->arena + g->weight_region_bytes, 0, g->arena_bytes - g->weight_region_bytes);
+    g->wbase = parent ? parent->wbase : g->arena;
+    char* const sbase = parent ? g->arena : g->arena + g->weight_region_bytes;
+    carve(g, g->wbase, sbase);
+    (void)hipMemset(sbase, 0, g->state_bytes);
+    if (opt && opt->own_stream) {  // a private stream: its priority decides the hardware queue it shares (profiles/NOTEBOOK.md §5)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);  // numerically: greatest <= 0 <= least
+        const int pr = opt->stream_priority > 0 ? greatest : opt->stream_priority < 0 ? least : 0;
+        e = hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, pr);
+        if (e != hipSuccess) {
+            (void)hipFree(g->arena);
+            delete g;
+            return hip_fail(e, "hipStreamCreateWithPriority(handle stream)", __FILE__, __LINE__);
+        }
+    }
     {
         GemvArgs a = base_gemv(g, g->wte, nullptr, c.vocab_size, c.n_embed, 0);
         a.prologue = PRO_LAYERNORM;
@@ -842,6 +901,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     {   // the widest input of a Block (mlp c_proj: 4 E floats per sequence) must fit the batched kernels' LDS
         GemvArgs a = base_gemv(g, g->layers[0].mlp_proj_w, nullptr, c.n_embed, 4 * c.n_embed, 0);
         if (!gemv_supported(a, g->wt)) {
+            if (g->stream) (void)hipStreamDestroy(g->stream);
             (void)hipFree(g->arena);
             delete g;
             set_error("batch %zu with n_embed %zu: %zu input rows of 4*n_embed floats do not fit the LDS (use a smaller batch)",
@@ -897,6 +957,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         g->st_on = gemv_pl4_ok(a1, g->wt) && gemv_pl4_ok(a3, g->wt) && gemv_pl4_ok(a4, g->wt) && gemv_pl4_ok(a5, g->wt);
     }
     if (g->lm_grid > 4096) {
+        if (g->stream) (void)hipStreamDestroy(g->stream);
         (void)hipFree(g->arena);
         delete g;
         set_error("lm_head grid %d exceeds the argmax partial buffer", g->lm_grid);
@@ -910,6 +971,7 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
         he = hipHostMalloc(reinterpret_cast<void**>(&g->h_ints), (batch * c.context_size + batch) * sizeof(int), hipHostMallocDefault);
     if (he != hipSuccess) {
         if (g->h_ctrl) (void)hipHostFree(g->h_ctrl);
+        if (g->stream) (void)hipStreamDestroy(g->stream);
         (void)hipFree(g->arena);
         delete g;
         return hip_fail(he, "hipHostMalloc(control mirrors)", __FILE__, __LINE__);
@@ -927,26 +989,31 @@ int zg_gpt_create(zg_gpt** out, const zg_gpt_config* config, size_t batch, unsig
     }
     {   // every decode graph is captured and instantiated here, not on the first forward that needs it
         int st = setup_prefetcher(g);
-        if (st == ZG_OK) st = capture_all(g, ctx().stream);
+        if (st == ZG_OK) st = capture_all(g, gs(g));
         if (st != ZG_OK) {
             drop_prefetcher(g);
             drop_graphs(g);
             (void)hipHostFree(g->h_ctrl);
             (void)hipHostFree(g->h_ints);
+            if (g->stream) (void)hipStreamDestroy(g->stream);
             (void)hipFree(g->arena);
             delete g;
             return st;
         }
     }
+    if (parent) ++parent->n_children;
     *out = g;
     return ZG_OK;
 }
 
 int zg_gpt_destroy(zg_gpt* g) {
     if (!g) return ZG_OK;
-    (void)hipStreamSynchronize(ctx().stream);
+    ZG_REQUIRE(g->n_children == 0, ZG_ERR_ARG, "zg_gpt_destroy: %d handle(s) still borrow this one's weights (destroy them first)", g->n_children);
+    (void)hipStreamSynchronize(gs(g));
     drop_prefetcher(g);
     drop_graphs(g);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->parent) --g->parent->n_children;
     (void)hipFree(g->arena);
     (void)hipHostFree(g->h_ctrl);
     (void)hipHostFree(g->h_ints);
@@ -954,9 +1021,17 @@ int zg_gpt_destroy(zg_gpt* g) {
     return ZG_OK;
 }
 
+int zg_gpt_stream(zg_gpt* g, void** hip_stream_out) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(g && hip_stream_out, ZG_ERR_ARG, "zg_gpt_stream: null argument");
+    *hip_stream_out = gs(g);
+    return ZG_OK;
+}
+
 int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src, size_t len) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && src && layer < g->cfg.n_layer, ZG_ERR_ARG, "load_block_tensor: bad argument");
+    ZG_REQUIRE(g->parent == nullptr, ZG_ERR_ARG, "load_block_tensor: this handle borrows its weights (load them into their owner)");
     const size_t E = g->cfg.n_embed;
     zg_layer& y = g->layers[layer];
     void* dst = nullptr;
@@ -979,13 +1054,13 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
     }
     ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "block slot %d expects %zu elements, got %zu", slot, n, len);
     g->ln_folded = false;
-    ZG_TRY(upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream));
+    ZG_TRY(upload_f32(src, n, dst, mat && g->wt == WT_BF16, gs(g)));
     if (mat && g->wt == WT_F32 && y.c_attn_p) {  // exact bf16 planes of the fp32 matrix for the whole-prompt GEMMs
         bf16_t* pl = slot == ZG_C_ATTN_W ? y.c_attn_p : slot == ZG_C_PROJ_W ? y.c_proj_p : slot == ZG_C_FC_W ? y.c_fc_p : y.mlp_proj_p;
         // plane-major [3][out][in]: the matrix as ONE row of out * in elements
         ZG_REQUIRE(n <= (size_t)2147483647 / 3, ZG_ERR_SHAPE, "weight matrix of %zu elements", n);  // (split3_kernel indexes 3 n in int)
-        ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), 1, (int)n, pl, ctx().stream));
-        ZG_HIP(hipStreamSynchronize(ctx().stream));
+        ZG_TRY(launch_split3(reinterpret_cast<const float*>(dst), 1, (int)n, pl, gs(g)));
+        ZG_HIP(hipStreamSynchronize(gs(g)));
     }
     return ZG_OK;
 }
@@ -993,6 +1068,7 @@ int zg_gpt_load_block_tensor(zg_gpt* g, size_t layer, int slot, const float* src
 int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && src, ZG_ERR_ARG, "load_tensor: bad argument");
+    ZG_REQUIRE(g->parent == nullptr, ZG_ERR_ARG, "load_tensor: this handle borrows its weights (load them into their owner)");
     const size_t E = g->cfg.n_embed;
     void* dst = nullptr;
     size_t n = 0;
@@ -1006,7 +1082,7 @@ int zg_gpt_load_tensor(zg_gpt* g, int slot, const float* src, size_t len) {
     }
     ZG_REQUIRE(len == n, ZG_ERR_SHAPE, "slot %d expects %zu elements, got %zu", slot, n, len);
     g->ln_folded = false;
-    return upload_f32(src, n, dst, mat && g->wt == WT_BF16, ctx().stream);
+    return upload_f32(src, n, dst, mat && g->wt == WT_BF16, gs(g));
 }
 
 int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes) {
@@ -1015,13 +1091,13 @@ int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes) {
     // ones before its bytes are copied, and a receiver must re-derive them from whatever lands in the region — also a
     // receiver that has run before (its flag would still say "folded").  So: fold now if needed (sender side: a few
     // small launches, drained), and mark the vectors stale for the next forward (receiver side: one re-fold).
-    if (!g->ln_folded) {
+    if (!root(g)->ln_folded) {
         ZG_TRY(require_init());
-        ZG_TRY(ensure_ln_folded(g, ctx().stream));
-        ZG_HIP(hipStreamSynchronize(ctx().stream));
+        ZG_TRY(ensure_ln_folded(g, gs(g)));
+        ZG_HIP(hipStreamSynchronize(gs(g)));
     }
-    g->ln_folded = false;
-    *device_ptr = g->arena;
+    root(g)->ln_folded = false;
+    *device_ptr = g->wbase;
     *bytes = g->weight_region_bytes;
     return ZG_OK;
 }
@@ -1033,7 +1109,7 @@ int zg_gpt_broadcast_weights(zg_gpt* g, int root, float* ms_out) {
     void* p = nullptr;
     size_t n = 0;
     ZG_TRY(zg_gpt_weight_arena(g, &p, &n));  // (sender: folded vectors valid; receiver: re-fold at the next forward)
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ms_out) {
         ZG_HIP(hipEventCreate(&e0));
@@ -1097,7 +1173,7 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
     const size_t V = g->cfg.vocab_size;
     ZG_REQUIRE(!logits_out || (compute_logits && logits_len >= g->batch * V), ZG_ERR_SHAPE,
                "gpt_forward: logits_out needs compute_logits and %zu elements", g->batch * V);
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     for (size_t b = 0; b < g->batch; ++b) {
         ZG_REQUIRE(tokens[b] < V, ZG_ERR_SHAPE, "gpt_forward: token %zu >= vocab %zu", tokens[b], V);
         g->h_ints[b] = (int)tokens[b];
@@ -1131,7 +1207,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
                "gpt_prefill: n_tokens %zu outside 1..%zu (stride %zu)", n_tokens, C, token_stride);
     ZG_REQUIRE(!logits_out || (compute_logits && logits_len >= B * V), ZG_ERR_SHAPE,
                "gpt_prefill: logits_out needs compute_logits and %zu elements", B * V);
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_HIP(hipStreamSynchronize(s));
     for (size_t b = 0; b < B; ++b)
         for (size_t i = 0; i < n_tokens; ++i) {
@@ -1163,7 +1239,7 @@ int zg_gpt_prefill(zg_gpt* g, const size_t* tokens, size_t token_stride, size_t 
 int zg_gpt_argmax(zg_gpt* g, size_t* tokens_out, size_t n_tokens) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && tokens_out && n_tokens == g->batch, ZG_ERR_ARG, "gpt_argmax: bad argument");
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_TRY(launch_embed_step(embed_args(g, 2), s));
     ZG_HIP(hipMemcpyAsync(g->h_ints, g->cur_token, g->batch * sizeof(int), hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
@@ -1178,7 +1254,7 @@ int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_toke
     const size_t V = g->cfg.vocab_size, B = g->batch;
     ZG_REQUIRE(!probs_out || probs_len >= B * V, ZG_ERR_SHAPE, "gpt_sample: probs_out needs %zu elements", B * V);
     ZG_TRY(zg_gpt_forward(g, seq_len, tokens, n_tokens, 1, nullptr, 0));  // main.zig:199
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     float* h_u = reinterpret_cast<float*>(g->h_ints);
     for (size_t b = 0; b < B; ++b) {
         if (uniforms) {
@@ -1207,20 +1283,23 @@ int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_toke
 int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && x_out && len >= g->batch * g->cfg.n_embed, ZG_ERR_ARG, "gpt_hidden: bad argument");
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_HIP(hipMemcpyAsync(x_out, g->x, g->batch * g->cfg.n_embed * sizeof(float),
                           is_device_ptr(x_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
     return check_fault(g);
 }
 
-int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens,
-                            size_t n_steps) {
-    ZG_TRY(require_init());
+// A generation in three parts, so that several handles' generations can be fed to their streams turn by turn
+// (zg_gpt_generate_enqueue_many): gen_begin — prompts, cache clearing, the whole-prompt pass, the prefetcher's start;
+// gen_pump — ONE graph launch (graph_steps decode steps) or one single step, false when nothing is left; gen_end — the
+// prefetcher's stop word and the record of the last pick.  After a successful gen_begin, gen_end must run (also on failure:
+// the prefetcher must not wait for steps that never come).
+static int gen_begin(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps) {
     ZG_REQUIRE(g && prompts && prompt_lens, ZG_ERR_ARG, "generate: null argument");
     const size_t C = g->cfg.context_size, V = g->cfg.vocab_size, B = g->batch;
     ZG_REQUIRE(n_steps >= 1 && n_steps <= C, ZG_ERR_SHAPE, "generate: n_steps %zu outside 1..%zu", n_steps, C);
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_HIP(hipStreamSynchronize(s));  // pinned staging below is shared with earlier calls
     size_t min_prompt = C;
     memset(g->h_ints, 0, (B * C + B) * sizeof(int));
@@ -1248,41 +1327,160 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
     ZG_TRY(clear_kv(g, s, first));
+    ZG_TRY(ensure_ln_folded(g, s));
     if (first > 0) {
         ZG_HIP(hipMemcpyAsync(g->out_tokens, g->prompt, B * C * sizeof(int), hipMemcpyDeviceToDevice, s));
         ZG_TRY(enqueue_prefill(g, first, false, s));
     }
-    ZG_TRY(ensure_ln_folded(g, s));
     if (!(g->flags & ZG_GPT_NO_GRAPH) && s != nullptr && g->graph_stream != s) ZG_TRY(capture_all(g, s));  // before the prefetcher starts its idle clock
     ZG_TRY(note_steps(g, n_steps, s));
     ZG_TRY(pf_start(g, n_steps, s));
-    int rs = ZG_OK;
+    g->gen_pos = first;
+    g->gen_n = n_steps;
+    g->gen_min_prompt = min_prompt;
+    g->gen_since_sync = 0;
+    g->gen_open = true;
+    return ZG_OK;
+}
+
+static int gen_pump(zg_gpt* g, bool* more) {
+    hipStream_t s = gs(g);
+    const size_t C = g->cfg.context_size, n_steps = g->gen_n, st = g->gen_pos;
+    *more = false;
+    if (st >= n_steps) return ZG_OK;
     const size_t K = ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) ? 1 : g->graph_steps;
     // ZGPT2_SYNC_EVERY=n (profiling only): drain the stream every n steps — rocprofv3's counter collection has crashed
     // on this stack when tens of thousands of dispatches were queued ahead of it
     static const int sync_every = env_int("ZGPT2_SYNC_EVERY", 0);
-    size_t since_sync = 0;
-    for (size_t st = first; st < n_steps && rs == ZG_OK;) {
-        if (sync_every > 0 && ++since_sync >= (size_t)sync_every) {
-            since_sync = 0;
-            (void)hipStreamSynchronize(s);
-        }
-        if (K > 1 && st >= min_prompt && st % K == 0 && st + K <= n_steps && st + K <= C) {
-            if (g->graph_stream != s) rs = capture_all(g, s);
-            const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
-            if (rs == ZG_OK) rs = capture_multi(g, b, s);
-            if (rs == ZG_OK && hipGraphLaunch(g->graphs_k[b], s) != hipSuccess) rs = ZG_ERR_HIP;
-            st += K;
-        } else {
-            rs = run_step(g, st >= min_prompt, st + 1, s);
-            ++st;
-        }
+    if (sync_every > 0 && ++g->gen_since_sync >= (size_t)sync_every) {
+        g->gen_since_sync = 0;
+        (void)hipStreamSynchronize(s);
     }
+    if (K > 1 && st >= g->gen_min_prompt && st % K == 0 && st + K <= n_steps && st + K <= C) {
+        if (g->graph_stream != s) ZG_TRY(capture_all(g, s));
+        const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
+        ZG_TRY(capture_multi(g, b, s));
+        ZG_HIP(hipGraphLaunch(g->graphs_k[b], s));
+        g->gen_pos = st + K;
+    } else {
+        ZG_TRY(run_step(g, st >= g->gen_min_prompt, st + 1, s));
+        g->gen_pos = st + 1;
+    }
+    *more = g->gen_pos < n_steps;
+    return ZG_OK;
+}
+
+static int gen_end(zg_gpt* g, int rs) {
+    hipStream_t s = gs(g);
+    g->gen_open = false;
     ZG_TRY(pf_stop(g, s));  // also after a failed launch: the prefetcher must not wait for steps that never come
     ZG_TRY(rs);
     ZG_TRY(launch_embed_step(embed_args(g, 1), s));  // record the pick of the last step
-    g->steps_enqueued = n_steps;
+    g->steps_enqueued = g->gen_n;
     return ZG_OK;
+}
+
+int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens,
+                            size_t n_steps) {
+    ZG_TRY(require_init());
+    ZG_TRY(gen_begin(g, prompts, prompt_stride, prompt_lens, n_steps));
+    int rs = ZG_OK;
+    for (bool more = true; more && rs == ZG_OK;) rs = gen_pump(g, &more);
+    return gen_end(g, rs);
+}
+
+// generate (src/main.zig:322-342) for the prompts of SEVERAL handles at once: independent sequences need not run in lock step
+// (the reference's batch restriction, ops.zig:126-128, lifted the other way) — every handle decodes its own prompts on its own
+// stream (zg_gpt_create_ex: own_stream) and the chip overlaps the chains, each of which leaves it idle across every one of its
+// launch boundaries.  The handles' graph launches are enqueued turn by turn: a hardware queue holds a fraction of a
+// generation's dispatches, and a host that fed one handle to the end first would block on that queue while the others idle.
+int zg_gpt_generate_enqueue_many(zg_gpt* const* handles, size_t n_handles, const size_t* prompts, size_t prompt_stride,
+                                 const size_t* prompt_lens, size_t n_steps) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(handles && n_handles >= 1 && n_handles <= 64 && prompts && prompt_lens, ZG_ERR_ARG, "generate_many: bad argument");
+    for (size_t i = 0; i < n_handles; ++i) {
+        ZG_REQUIRE(handles[i] != nullptr, ZG_ERR_ARG, "generate_many: handle %zu is null", i);
+        for (size_t j = 0; j < i; ++j) {
+            ZG_REQUIRE(handles[i] != handles[j], ZG_ERR_ARG, "generate_many: handle %zu is handle %zu", i, j);
+            ZG_REQUIRE(n_handles == 1 || gs(handles[i]) != gs(handles[j]), ZG_ERR_ARG,
+                       "generate_many: handles %zu and %zu share a stream (create them with own_stream)", j, i);
+        }
+    }
+    size_t begun = 0, row = 0;
+    int rs = ZG_OK;
+    for (; begun < n_handles && rs == ZG_OK; ++begun) {
+        rs = gen_begin(handles[begun], prompts + row * prompt_stride, prompt_stride, prompt_lens + row, n_steps);
+        if (rs != ZG_OK) break;  // (its message is picked up below)
+        row += handles[begun]->batch;
+    }
+    char msg[512] = "";
+    static const int feeders = env_int("ZGPT2_MANY_THREADS", 1);
+    if (rs == ZG_OK && feeders && begun > 1) {
+        // one feeder thread per handle: a hipGraphLaunch returns only when its hardware queue has room for the graph's
+        // dispatches, so one thread feeding all queues in turn stands still whenever the slowest chain's queue is full
+        std::vector<std::thread> th;
+        std::vector<int> res(begun, ZG_OK);
+        std::vector<std::string> errs(begun);
+        const int dev = ctx().device;
+        for (size_t i = 0; i < begun; ++i)
+            th.emplace_back([&, i]() {
+                int r = hipSetDevice(dev) == hipSuccess ? ZG_OK : ZG_ERR_HIP;
+                for (bool more = true; more && r == ZG_OK;) r = gen_pump(handles[i], &more);
+                res[i] = r;
+                if (r != ZG_OK) errs[i] = zg_last_error();  // (the message is thread-local)
+            });
+        for (auto& t : th) t.join();
+        for (size_t i = 0; i < begun && rs == ZG_OK; ++i)
+            if (res[i] != ZG_OK) {
+                rs = res[i];
+                snprintf(msg, sizeof msg, "%s", errs[i].c_str());
+            }
+    } else {
+        bool any = rs == ZG_OK;
+        while (any && rs == ZG_OK) {
+            any = false;
+            for (size_t i = 0; i < begun && rs == ZG_OK; ++i) {
+                bool more = false;
+                if (handles[i]->gen_pos < handles[i]->gen_n) rs = gen_pump(handles[i], &more);
+                any |= more;
+            }
+        }
+        if (rs != ZG_OK) snprintf(msg, sizeof msg, "%s", zg_last_error());
+    }
+    int first_err = rs;
+    for (size_t i = 0; i < begun; ++i) {
+        const int e = gen_end(handles[i], rs);
+        if (first_err == ZG_OK && e != ZG_OK) {
+            first_err = e;
+            snprintf(msg, sizeof msg, "%s", zg_last_error());
+        }
+    }
+    if (first_err != ZG_OK) set_error("%s", msg);
+    return first_err;
+}
+
+int zg_gpt_generate_fetch_many(zg_gpt* const* handles, size_t n_handles, size_t n_steps, size_t* out_tokens, size_t out_len) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(handles && n_handles >= 1 && out_tokens, ZG_ERR_ARG, "generate_fetch_many: null argument");
+    size_t rows = 0;
+    for (size_t i = 0; i < n_handles; ++i) {
+        ZG_REQUIRE(handles[i] != nullptr, ZG_ERR_ARG, "generate_fetch_many: handle %zu is null", i);
+        rows += handles[i]->batch;
+    }
+    ZG_REQUIRE(out_len >= rows * n_steps, ZG_ERR_SHAPE, "generate_fetch_many: out_tokens too short");
+    size_t row = 0;
+    int first_err = ZG_OK;
+    char msg[512];
+    for (size_t i = 0; i < n_handles; ++i) {  // every handle is drained, also behind a failed one
+        const int e = zg_gpt_generate_fetch(handles[i], n_steps, out_tokens + row * n_steps, handles[i]->batch * n_steps);
+        if (first_err == ZG_OK && e != ZG_OK) {
+            first_err = e;
+            snprintf(msg, sizeof msg, "%s", zg_last_error());
+        }
+        row += handles[i]->batch;
+    }
+    if (first_err != ZG_OK) set_error("%s", msg);
+    return first_err;
 }
 
 int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t out_len) {
@@ -1290,7 +1488,7 @@ int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t 
     ZG_REQUIRE(g && out_tokens, ZG_ERR_ARG, "generate_fetch: null argument");
     const size_t C = g->cfg.context_size, B = g->batch;
     ZG_REQUIRE(n_steps <= C && out_len >= B * n_steps, ZG_ERR_SHAPE, "generate_fetch: out_tokens too short");
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_HIP(hipMemcpyAsync(g->h_ints, g->out_tokens, B * C * sizeof(int), hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
     ZG_TRY(check_fault(g));
@@ -1311,7 +1509,7 @@ int zg_gpt_profile_step(zg_gpt* g, size_t seq_len, int iters, float* us_out, siz
     ZG_REQUIRE(g && us_out && n_out >= 8 && iters > 0, ZG_ERR_ARG, "profile_step: bad argument");
     ZG_REQUIRE(seq_len >= 1 && seq_len + (size_t)iters - 1 <= g->cfg.context_size, ZG_ERR_SHAPE,
                "profile_step: positions %zu..%zu outside the context", seq_len, seq_len + iters - 1);
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_HIP(hipStreamSynchronize(s));
     ZG_TRY(ensure_ln_folded(g, s));
     ZG_TRY(note_steps(g, (size_t)iters, s));
@@ -1357,7 +1555,7 @@ int zg_gpt_time_kernel(zg_gpt* g, int which_and_options, int iters, float* avg_u
     const bool cycle = (which_and_options & ZG_TIME_WALK_LAYERS) != 0;  // walk the layers, so that no launch finds its weights in the L2s
     const size_t t_opt = (size_t)((unsigned)which_and_options >> 16);    // another position for the attention kernel (0: mid-context)
     ZG_REQUIRE(g && avg_us && iters > 0 && which_and_options >= 0 && which <= 6, ZG_ERR_ARG, "time_kernel: bad argument");
-    hipStream_t s = ctx().stream;
+    hipStream_t s = gs(g);
     ZG_REQUIRE(s != nullptr, ZG_ERR_UNSUPPORTED, "time_kernel needs a capturable stream");
     const size_t E = g->cfg.n_embed, wb = g->wbytes;
     const size_t bytes_tab[7] = {0, 3 * E * E * wb, 0, E * E * wb, 4 * E * E * wb, 4 * E * E * wb, g->cfg.vocab_size * E * wb};
@@ -1413,7 +1611,7 @@ int zg_debug_prefetch_stats(zg_gpt* g, unsigned* out, size_t n_out) {
     memset(out, 0, n_out * sizeof(unsigned));
     out[0] = g->pf_on ? (g->pf_stalled ? 2u : 1u) : 0u;
     if (!g->pf_on) return ZG_OK;
-    ZG_HIP(hipStreamSynchronize(ctx().stream));
+    ZG_HIP(hipStreamSynchronize(gs(g)));
     ZG_HIP(hipStreamSynchronize(g->pf_stream));
     PfCtl h;
     ZG_HIP(hipMemcpy(&h, g->pf_ctl, sizeof(PfCtl), hipMemcpyDeviceToHost));

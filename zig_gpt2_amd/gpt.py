@@ -17,7 +17,9 @@ from .synth import GPTConfig
 
 class GPT:
     def __init__(self, config: GPTConfig, batch=1, weights_f32=False, use_graph=True, kv_f16=False, prefill=True,
-                 prefill_planes=3, prefetch=True, kv_b24=False):
+                 prefill_planes=3, prefetch=True, kv_b24=False, share_weights_with=None, own_stream=False, stream_priority=0):
+        """share_weights_with / own_stream / stream_priority: zg_gpt_options of zg_gpt_create_ex (a handle of an independent
+        prompt group on the same GPU: private stream, weight region borrowed from another GPT of the same config)."""
         self.config, self.batch = config, batch
         L = _lib.load()
         flags = (_lib.GPT_WEIGHTS_F32 if weights_f32 else 0) | (0 if use_graph else _lib.GPT_NO_GRAPH)
@@ -28,7 +30,12 @@ class GPT:
         flags |= 0 if prefetch else _lib.GPT_NO_PREFETCH
         cfg = _lib.GptConfig(config.vocab_size, config.context_size, config.n_layer, config.n_heads, config.n_embed)
         h = C.c_void_p()
-        check(L.zg_gpt_create(C.byref(h), C.byref(cfg), batch, flags))
+        if share_weights_with is None and not own_stream:
+            check(L.zg_gpt_create(C.byref(h), C.byref(cfg), batch, flags))
+        else:
+            opt = _lib.GptOptions(share_weights_with.h if share_weights_with is not None else None, int(bool(own_stream)), int(stream_priority))
+            check(L.zg_gpt_create_ex(C.byref(h), C.byref(cfg), batch, flags, C.byref(opt)))
+        self._weight_owner = share_weights_with  # keeps the owner alive: it must be destroyed last
         self.h = h
         self._L = L
 
@@ -158,6 +165,79 @@ class GPT:
         us, nbytes = C.c_float(), C.c_size_t()
         check(self._L.zg_gpt_time_kernel(self.h, which | (0x100 if walk_layers else 0) | (int(at) << 16), iters, C.byref(us), C.byref(nbytes)))
         return us.value, nbytes.value
+
+
+class GPTGroups:
+    """`n_prompts` independent prompts on ONE GPU as `groups` handles of n_prompts / groups sequences each, every handle on
+    its own stream, all reading one weight region (zg_gpt_create_ex) — the embarrassingly parallel case of the reference's
+    generate loop (src/main.zig:322-342) with the batch == 1 restriction of src/ops.zig:126-128 lifted by running chains side
+    by side instead of in lock step.  groups == 1 is a plain GPT of batch n_prompts.  Tokens equal GPT's row for row."""
+
+    # priorities dealt to the groups' streams: streams of different priorities never share a hardware queue
+    PRIORITIES = (0, 1, -1)
+
+    def __init__(self, config: GPTConfig, n_prompts, groups, priorities=None, **kw):
+        assert groups >= 1 and n_prompts % groups == 0, (n_prompts, groups)
+        self.config, self.n_prompts, self.groups = config, n_prompts, groups
+        self._L = _lib.load()
+        per = n_prompts // groups
+        pr = priorities if priorities is not None else [self.PRIORITIES[i % len(self.PRIORITIES)] for i in range(groups)]
+        self.members = []
+        for i in range(groups):
+            self.members.append(GPT(config, batch=per, share_weights_with=self.members[0] if i else None,
+                                    own_stream=groups > 1, stream_priority=pr[i], **kw))
+        self._harr = (C.c_void_p * groups)(*[m.h for m in self.members])
+
+    @property
+    def batch(self):
+        return self.n_prompts
+
+    def close(self):
+        for m in reversed(getattr(self, "members", [])):  # the weight owner last
+            m.close()
+        self.members = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, weights):
+        self.members[0].load_weights(weights)
+
+    def _prompts(self, prompts):
+        prompts = [np.atleast_1d(np.asarray(p, dtype=np.uint64)) for p in prompts]
+        assert len(prompts) == self.n_prompts
+        stride = max(len(p) for p in prompts)
+        mat = np.zeros((self.n_prompts, stride), np.uint64)
+        lens = np.zeros(self.n_prompts, np.uint64)
+        for b, p in enumerate(prompts):
+            mat[b, : len(p)] = p
+            lens[b] = len(p)
+        return mat, lens, stride
+
+    def generate_enqueue(self, prompts, n_steps):
+        mat, lens, stride = self._prompts(prompts)
+        check(self._L.zg_gpt_generate_enqueue_many(self._harr, self.groups, ptr(mat), stride, ptr(lens), n_steps))
+
+    def generate_fetch(self, n_steps):
+        out = np.zeros((self.n_prompts, n_steps), np.uint64)
+        check(self._L.zg_gpt_generate_fetch_many(self._harr, self.groups, n_steps, ptr(out), out.size))
+        return out
+
+    def generate(self, prompts, n_steps):
+        self.generate_enqueue(prompts, n_steps)
+        return self.generate_fetch(n_steps)
+
+    def synchronize(self):
+        """Drain every member's stream (hipStreamSynchronize through zg_gpt_hidden's drain would copy; use the streams)."""
+        import torch
+
+        for m in self.members:
+            s = C.c_void_p()
+            check(self._L.zg_gpt_stream(m.h, C.byref(s)))
+            torch.cuda.ExternalStream(s.value).synchronize()
 
 
 # --------------------------------------------------------------------------------------------
