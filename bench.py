@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-prefetch", action="store_true", help="no side-stream L2 prefetcher beside the decode chain (A/B)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-op-tier", action="store_true", help="skip the timing of the literal drop-in (zgpt2_main over the op tier)")
     p.add_argument("--no-other-configs", action="store_true", help="skip the secondary block (8 prompts, XL, nano-char)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     p.add_argument("--seed", type=int, default=0)
@@ -180,6 +181,38 @@ def cpu_baseline(cfg, weights, prompt, budget_s):
         "sample": f"oracle GPT.forward fp32, {blas}: {n_win} tokens at T={lo0}.. ({1e3 * t_lo:.1f} ms/tok) and "
                   f"{n_win} at T={hi0}.. ({1e3 * t_hi:.1f} ms/tok); whole 1..{ctx} run priced by the affine fit",
     }
+
+
+def op_tier(model_name, seed, prompt, ctx, cpu_value):
+    """The LITERAL drop-in timed: src/main.zig's dataflow (State, Block.forward, GPT.forward, generate with greedy argmax) over
+    the op tier — host buffers, one synchronous FFI call per op, 77 per token at 124M — run by the compiled C++ caller
+    zig_gpt2_amd/bin/zgpt2_main as a child process (what an unchanged main.zig over zig/ops.zig would do; fp32 weights
+    mirrored once at Linear.init, caller-owned KV caches mirrored on the device).  The whole 1..ctx run, no extrapolation."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "zig_gpt2_amd", "bin", "zgpt2_main")
+    if not os.path.exists(exe):
+        return {"error": f"{exe} is not built"}
+    args = [exe, model_name, str(seed), ",".join(str(int(t)) for t in prompt), str(ctx)]
+    t0 = time.perf_counter()
+    out = subprocess.run(args, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stderr.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": f"zgpt2_main rc {out.returncode}: {out.stderr[-300:]}"}
+    d = json.loads(lines[-1])
+    ids = [int(t) for t in out.stdout.split()]
+    return {"value": d["tokens_per_s"], "unit": "tokens/s", "steps": d["steps"], "seconds": d["seconds"],
+            "first_64_tokens_per_s": d["first_64_tokens_per_s"], "calls_per_token": 2 + 6 * synth_layers(model_name) + 2,
+            "vs_cpu_baseline": round(d["tokens_per_s"] / cpu_value, 2) if cpu_value else None,
+            "first_tokens": ids[:8], "process_seconds": round(time.perf_counter() - t0, 1),
+            "how": "zgpt2_main <model> <seed> <prompt> <ctx> (op tier: the default), timing of its generate loop from its stderr; "
+                   "weights = the same synthetic seed as the headline run, kept fp32 as the reference keeps them"}
+
+
+def synth_layers(model_name):
+    from zig_gpt2_amd import synth
+
+    return synth.CONFIGS[model_name].n_layer
 
 
 def kernel_table(model, lib, cfg, ppg, wsz, kv_elem):
@@ -618,6 +651,13 @@ def main():
     }
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, weights, prompts[0], a.cpu_seconds)
+    if world == 1 and not a.no_op_tier and a.model in ("124M", "nano-char", "tiny") and not a.weights_f32:
+        try:
+            out["op_tier"] = op_tier(a.model, a.seed, prompts[0], ctx, out.get("cpu_baseline", {}).get("value"))
+            if "first_tokens" in out["op_tier"]:  # same weights, same prompt: the literal drop-in and the model tier agree
+                out["op_tier"]["tokens_equal_model_tier"] = out["op_tier"]["first_tokens"] == out["first_tokens"]
+        except Exception as e:
+            out["op_tier"] = {"error": str(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

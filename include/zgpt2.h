@@ -12,10 +12,14 @@
  *   - Lengths are ELEMENT counts (Zig slice .len), not bytes.  f32 is IEEE binary32, usize is
  *     size_t (8 bytes).
  *   - Op tier: every pointer may be host memory or device memory (detected with
- *     hipPointerGetAttributes).  Host buffers are staged through an arena that is allocated once
+ *     hipPointerGetAttributes).  Host buffers are staged through arenas that are allocated once
  *     in zg_init — no *_forward call allocates device or host memory (the reference's
- *     "no allocations at runtime" contract, README.md:6, src/main.zig:46-64).  Op-tier calls are
- *     synchronous on return, because the reference's host code reads the buffers next
+ *     "no allocations at runtime" contract, README.md:6, src/main.zig:46-64): a device arena
+ *     (ZGPT2_STAGING_MB, 512), a pinned host arena (ZGPT2_PINNED_MB, 32) through which the caller's
+ *     pageable buffers travel — small vectors that a kernel touches once are read / written by the
+ *     kernel in place across PCIe, the rest moves by one DMA each way — and a device pool for the
+ *     mirrors of caller-owned KV caches (ZGPT2_KV_MIRROR_MB, 1024; see zg_attn_forward).  Op-tier
+ *     calls are synchronous on return, because the reference's host code reads the buffers next
  *     (src/main.zig:136-145).
  *   - Model tier: weights, KV cache and every scratch buffer live in one device arena created by
  *     zg_gpt_create; zg_gpt_forward/zg_gpt_generate_greedy only launch kernels.
@@ -60,7 +64,8 @@ int zg_synchronize(void);
  * q / k / v) are never looked up, so a freed weight's address may be reused for them.  Re-registering an
  * address replaces its mirror; host weights changed in place after registration must be registered
  * again.  zg_unregister_tensor drops one mirror (the `defer allocator.free(weight)` moment of
- * src/tests.zig). */
+ * src/tests.zig) — also the KV-cache mirror zg_attn_forward keeps for that address; zg_unregister_all
+ * drops every mirror and empties the KV pool. */
 int zg_register_tensor(const float* host_ptr, size_t len);
 int zg_unregister_tensor(const float* host_ptr);
 int zg_unregister_all(void);
@@ -90,7 +95,14 @@ int zg_layernorm_forward(size_t n_features, const float* weight, const float* bi
  * [seq_len*E], _attn [seq_len] are the reference's scratch slices; on return _qkv holds the
  * c_attn output and _q the merged heads (ops.zig:171) as in the reference, while _k/_v/_attn
  * (pure scratch whose content no caller reads) are left untouched: the kernel attends over the
- * [T, H, hd] cache in place instead of re-transposing it every step (ops.zig:153,158). */
+ * [T, H, hd] cache in place instead of re-transposing it every step (ops.zig:153,158).
+ * HOST caches are mirrored on the device, keyed by the cache's address: a call that continues the
+ * sequence the mirror holds (same pointer, same n_embed, seq_len = rows held + 1 — the only pattern
+ * src/main.zig:331-338 produces) uploads nothing and returns only row seq_len-1 to the caller's
+ * buffer; any other call (first sight, position 1 again, a jump, a repeated position) uploads rows
+ * 0..seq_len-2 from the caller's buffer first.  A caller that EDITS rows it already handed over and
+ * then continues with the next position must drop the mirror first (zg_unregister_tensor(cache)).
+ * When the pool has no room for a cache, that cache is staged whole on every call, as before. */
 int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight,
                     const float* c_attn_bias, const float* c_proj_weight, const float* c_proj_bias,
                     size_t seq_len, const float* inputs, size_t inputs_len, float* k_cache,

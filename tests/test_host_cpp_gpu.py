@@ -55,3 +55,23 @@ def test_cpp_host_reads_the_raw_weight_directory(tmp_path, tier):
     bad = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
     assert bad.returncode != 0 and "size does not match" in bad.stderr
 
+
+
+def test_cpp_host_op_tier_at_124m_matches_oracle_and_reports_its_speed():
+    """The literal drop-in at full size: main.zig's dataflow over the op tier (host buffers, one FFI call per op, fp32
+    weights mirrored once, the KV caches mirrored on the device) for GPT-2 124M x 64 positions — BASELINE configs[0]'s
+    workload — token for token the oracle's; the program reports tokens/s on stderr."""
+    import json
+
+    cfg = synth.CONFIGS["124M"]
+    prompt = synth.rand_tokens(1000, 1, cfg.vocab_size)
+    args = [BIN, "124M", "0", ",".join(str(int(t)) for t in prompt), "64"]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    ids = np.array([int(t) for t in out.stdout.split()], dtype=np.uint64)
+    ref = oracle.GPT(cfg, synth.make_weights(cfg, seed=0, bf16=True)).generate_greedy(prompt, 64)
+    assert np.array_equal(ids, ref), (ids, ref)
+    line = [l for l in out.stderr.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["tier"] == "op" and d["steps"] == 64 and d["tokens_per_s"] > 0
+    print(f"op tier, 124M x 64: {d['tokens_per_s']} tokens/s")

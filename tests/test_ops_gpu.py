@@ -291,6 +291,56 @@ def test_attn_forward_long_incremental(zg):
     assert_ref_close(ref.v_cache, v_cache, "v_cache")
 
 
+def test_attn_forward_cache_mirror_follows_the_callers_cache(zg):
+    """zg_attn_forward keeps a device mirror of a caller-owned HOST cache (keyed by its address) and uploads nothing while the
+    caller walks the positions in order; whatever else the caller does — restart at position 1 with other inputs, jump ahead
+    over rows it filled itself, repeat a position, swap the two caches, drop the mirror after editing a row — the result must
+    be what the reference computes from the cache contents the caller holds (ops.zig:129-173)."""
+    e, hds, T = 128, 2, 40
+    caw = synth.fill_normal(170, 3 * e * e, 0, 0.08).reshape(3 * e, e)
+    cab = synth.fill_normal(171, 3 * e, 0, 0.05)
+    cpw = synth.fill_normal(172, e * e, 0, 0.08).reshape(e, e)
+    cpb = synth.fill_normal(173, e, 0, 0.05)
+    attn = ops.CausalSelfAttention(hds, e, ops.Linear(e, 3 * e, caw, cab), ops.Linear(e, e, cpw, cpb))
+    k_cache, v_cache = z(T * e), z(T * e)
+    _qkv, _q, _k, _v, _attn = z(3 * e), z(e), z(T * e), z(T * e), z(T)
+
+    def step(ref, t, x, kc=None, vc=None):
+        kc, vc = (k_cache if kc is None else kc), (v_cache if vc is None else vc)
+        out = z(e)
+        attn.forward(t, x, kc[: t * e], vc[: t * e], out, _qkv, _q, _k[: t * e], _v[: t * e], _attn[:t])
+        assert_ref_close(ref.forward(t, x), out, f"position {t}", scale_floor=2e-6)
+        assert_ref_close(ref.k_cache[: t * e], kc[: t * e], f"k rows at {t}")
+        assert_ref_close(ref.v_cache[: t * e], vc[: t * e], f"v rows at {t}")
+        assert_ref_close(ref._qkv, _qkv, f"_qkv at {t}")  # what the reference leaves in its scratch (ops.zig:143,171)
+        assert_ref_close(ref._q, _q, f"_q at {t}")
+
+    xs = synth.fill_normal(174, 3 * T * e, 0, 1.0).reshape(3 * T, e)
+    ref = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, T)
+    for t in range(1, 13):               # in order: the mirror is extended row by row
+        step(ref, t, xs[t])
+    ref = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, T)
+    for t in range(1, 6):                # a new sequence on the same buffers
+        step(ref, t, xs[T + t])
+    # the caller fills rows 5..8 itself (another producer), then continues at position 10: a jump
+    fill_k, fill_v = synth.fill_normal(175, 4 * e, 0, 0.5), synth.fill_normal(176, 4 * e, 0, 0.5)
+    for c, f in ((k_cache, fill_k), (ref.k_cache, fill_k), (v_cache, fill_v), (ref.v_cache, fill_v)):
+        c[5 * e: 9 * e] = f
+    step(ref, 10, xs[2 * T])
+    step(ref, 10, xs[2 * T + 1])         # the same position again (row 9 overwritten)
+    step(ref, 11, xs[2 * T + 2])
+    # edit an earlier row in place and drop the mirror, as the header prescribes
+    k_cache[2 * e: 3 * e] = 0.25
+    ref.k_cache[2 * e: 3 * e] = 0.25
+    from zig_gpt2_amd import _lib
+    _lib.check(zg.zg_unregister_tensor(_lib.ptr(k_cache)))
+    step(ref, 12, xs[2 * T + 3])
+    # the roles of the two buffers swapped: keys in what was the value cache
+    ref2 = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, T)
+    for t in range(1, 5):
+        step(ref2, t, xs[t + 20], kc=v_cache, vc=k_cache)
+
+
 def test_error_behaviour(zg):
     x = z(10)
     assert zg.zg_layernorm_forward(768, x.ctypes.data, x.ctypes.data, 1e-5, x.ctypes.data, 10) == -2  # ZG_ERR_SHAPE

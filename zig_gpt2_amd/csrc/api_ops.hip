@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "zg_runtime.h"
 
 namespace zg {
@@ -59,7 +61,7 @@ bool is_device_ptr(const void* p) {
 }
 
 // ------------------------------------------------------------------------------------- Call
-Call::Call() : mark_(ctx().stage_off), s_(ctx().stream) {}
+Call::Call() : mark_(ctx().stage_off), pin_mark_(ctx().pin_off), s_(ctx().stream) {}
 
 int Call::alloc(size_t bytes, void** dev) {
     Ctx& c = ctx();
@@ -73,18 +75,25 @@ int Call::alloc(size_t bytes, void** dev) {
     return ZG_OK;
 }
 
+char* Call::pin_alloc(size_t bytes) {  // nullptr: does not fit (the caller takes the pageable path)
+    Ctx& c = ctx();
+    const size_t off = (c.pin_off + 255) & ~(size_t)255;
+    if (c.pin == nullptr || off + bytes > c.pin_cap) return nullptr;
+    c.pin_off = off + bytes;
+    return c.pin + off;
+}
+
 size_t Call::arena_left() const {
     const Ctx& c = ctx();
     const size_t off = (c.stage_off + 255) & ~(size_t)255;
     return off < c.stage_cap ? c.stage_cap - off : 0;
 }
 
-int Call::stage_in(const void* p, size_t bytes, bool is_param, const void** dev) {
+// what a kernel may touch in place over PCIe: a few wavefronts' worth of traffic, not a matrix
+static constexpr size_t kZeroCopyMax = (size_t)1 << 20;
+
+int Call::stage_in(const void* p, size_t bytes, bool is_param, bool once, const void** dev) {
     if (bytes == 0 || p == nullptr) {
-        *dev = p;
-        return ZG_OK;
-    }
-    if (is_device_ptr(p)) {
         *dev = p;
         return ZG_OK;
     }
@@ -98,14 +107,26 @@ int Call::stage_in(const void* p, size_t bytes, bool is_param, const void** dev)
             return ZG_OK;
         }
     }
+    if (is_device_ptr(p)) {
+        *dev = p;
+        return ZG_OK;
+    }
+    char* pin = pin_alloc(bytes);
+    if (pin != nullptr) {
+        memcpy(pin, p, bytes);
+        if (once && bytes <= kZeroCopyMax) {
+            *dev = pin;
+            return ZG_OK;
+        }
+    }
     void* d = nullptr;
     ZG_TRY(alloc(bytes, &d));
-    ZG_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, s_));
+    ZG_HIP(hipMemcpyAsync(d, pin ? pin : p, bytes, hipMemcpyHostToDevice, s_));
     *dev = d;
     return ZG_OK;
 }
 
-int Call::stage_out(void* p, size_t bytes, bool copy_in, void** dev) {
+int Call::stage_out(void* p, size_t bytes, bool copy_in, bool once, void** dev) {
     if (bytes == 0 || p == nullptr) {
         *dev = p;
         return ZG_OK;
@@ -114,26 +135,78 @@ int Call::stage_out(void* p, size_t bytes, bool copy_in, void** dev) {
         *dev = p;
         return ZG_OK;
     }
-    ZG_REQUIRE(n_outs_ < 16, ZG_ERR_STAGING, "too many staged outputs");
+    ZG_REQUIRE(n_outs_ < 24, ZG_ERR_STAGING, "too many staged outputs");
+    char* pin = pin_alloc(bytes);
+    if (pin != nullptr && copy_in) memcpy(pin, p, bytes);
+    if (pin != nullptr && once && bytes <= kZeroCopyMax) {  // the kernel stores straight into the pinned slot
+        outs_[n_outs_++] = Out{p, nullptr, pin, bytes};
+        *dev = pin;
+        return ZG_OK;
+    }
     void* d = nullptr;
     ZG_TRY(alloc(bytes, &d));
-    if (copy_in) ZG_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, s_));
-    outs_[n_outs_++] = Out{p, d, bytes};
+    if (copy_in) ZG_HIP(hipMemcpyAsync(d, pin ? pin : p, bytes, hipMemcpyHostToDevice, s_));
+    outs_[n_outs_++] = Out{p, d, pin, bytes};
     *dev = d;
     return ZG_OK;
 }
 
+int Call::also_out(void* host, const void* dev_part, size_t bytes) {
+    if (bytes == 0 || host == nullptr || is_device_ptr(host)) return ZG_OK;
+    ZG_REQUIRE(n_outs_ < 24, ZG_ERR_STAGING, "too many staged outputs");
+    // inside an output that travels through the pinned arena anyway: the CPU copies from there, no second transfer
+    const char* d = static_cast<const char*>(dev_part);
+    for (int i = 0; i < n_outs_; ++i) {
+        const char* base = static_cast<const char*>(outs_[i].dev);
+        if (base != nullptr && outs_[i].pin != nullptr && d >= base && d + bytes <= base + outs_[i].bytes) {
+            outs_[n_outs_++] = Out{host, nullptr, outs_[i].pin + (d - base), bytes};
+            return ZG_OK;
+        }
+    }
+    outs_[n_outs_++] = Out{host, const_cast<void*>(dev_part), pin_alloc(bytes), bytes};
+    return ZG_OK;
+}
+
 int Call::finish() {
+    for (int i = 0; i < n_outs_; ++i) {
+        if (outs_[i].dev == nullptr) continue;
+        // outputs that lie back to back in both arenas (consecutive out() calls of 256-byte multiples) leave in ONE transfer
+        size_t bytes = outs_[i].bytes;
+        int j = i;
+        while (outs_[i].pin != nullptr && j + 1 < n_outs_ && outs_[j + 1].dev != nullptr && outs_[j + 1].pin != nullptr &&
+               static_cast<char*>(outs_[i].dev) + bytes == static_cast<char*>(outs_[j + 1].dev) && outs_[i].pin + bytes == outs_[j + 1].pin) {
+            bytes += outs_[j + 1].bytes;
+            ++j;
+        }
+        ZG_HIP(hipMemcpyAsync(outs_[i].pin ? (void*)outs_[i].pin : outs_[i].host, outs_[i].dev, bytes, hipMemcpyDeviceToHost, s_));
+        i = j;
+    }
+    // Op-tier calls are synchronous on return: the reference's host code reads the buffers next.  The host polls a pinned
+    // completion word stored in stream order behind the call's work (cheaper than the runtime's wake-up); every 256th call —
+    // and any call whose word does not arrive — drains the stream the ordinary way, which also surfaces asynchronous errors.
+    Ctx& c = ctx();
+    bool drained = false;
+    if (c.done_flag != nullptr && ++c.calls_since_sync < 256) {
+        const unsigned seq = ++c.done_seq;
+        if (launch_done_flag(c.done_flag, seq, s_) == ZG_OK)
+            for (long spins = 0; spins < (1L << 24) && !drained; ++spins) {
+                drained = __atomic_load_n(c.done_flag, __ATOMIC_ACQUIRE) == seq;
+                if (!drained) __builtin_ia32_pause();
+            }
+    }
+    if (!drained) {
+        ZG_HIP(hipStreamSynchronize(s_));
+        c.calls_since_sync = 0;
+    }
     for (int i = 0; i < n_outs_; ++i)
-        ZG_HIP(hipMemcpyAsync(outs_[i].host, outs_[i].dev, outs_[i].bytes, hipMemcpyDeviceToHost, s_));
-    // Op-tier calls are synchronous on return: the reference's host code reads the buffers next.
-    ZG_HIP(hipStreamSynchronize(s_));
-    ctx().stage_off = mark_;
+        if (outs_[i].pin != nullptr) memcpy(outs_[i].host, outs_[i].pin, outs_[i].bytes);
+    c.stage_off = mark_;
+    c.pin_off = pin_mark_;
     n_outs_ = 0;
     return ZG_OK;
 }
 
-// A failed call must still release the arena.
+// A failed call must still release the arenas.
 struct CallGuard {
     Call& c;
     bool done = false;
@@ -142,6 +215,7 @@ struct CallGuard {
         if (!done) {
             (void)hipStreamSynchronize(c.stream());
             ctx().stage_off = 0;
+            ctx().pin_off = 0;
         }
     }
 };
@@ -286,6 +360,14 @@ extern "C" {
 
 const char* zg_last_error(void) { return zg::g_err; }
 
+static size_t env_mb(const char* name, size_t dflt) {
+    if (const char* e = getenv(name)) {
+        const long v = atol(e);
+        if (v >= 0) return (size_t)v;
+    }
+    return dflt;
+}
+
 int zg_init_ex(int device, size_t staging_bytes) {
     Ctx& c = ctx();
     if (c.inited) {
@@ -304,8 +386,20 @@ int zg_init_ex(int device, size_t staging_bytes) {
     c.stream = c.own_stream;
     c.stage_cap = staging_bytes;
     ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.stage), c.stage_cap));
-    ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_flag), sizeof(int)));
-    ZG_HIP(hipMemset(c.d_flag, 0, sizeof(int)));
+    // pinned twin of the staging arena for the small host buffers of src/main.zig's State (a few KB each; the logits 200 KB)
+    c.pin_cap = std::min(staging_bytes, env_mb("ZGPT2_PINNED_MB", 32) << 20);
+    if (c.pin_cap > 0) ZG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pin), c.pin_cap, hipHostMallocDefault));
+    c.pin_off = 0;
+    // device pool for the mirrors of caller-owned KV caches (zg_attn_forward): 124M needs 75 MB, GPT-2 XL 630 MB of 288 GB
+    c.kv_pool_cap = env_mb("ZGPT2_KV_MIRROR_MB", 1024) << 20;
+    if (c.kv_pool_cap > 0) ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.kv_pool), c.kv_pool_cap));
+    c.kv_pool_off = 0;
+    ZG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.d_flag), 64, hipHostMallocDefault));
+    *c.d_flag = 0;
+    c.done_flag = reinterpret_cast<unsigned*>(c.d_flag) + 8;
+    *c.done_flag = 0;
+    c.done_seq = c.calls_since_sync = 0;
+    if (env_mb("ZGPT2_OP_POLL", 1) == 0) c.done_flag = nullptr;  // measurement switch: drain every op-tier call with hipStreamSynchronize
     ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_zero), 64));
     ZG_HIP(hipMemset(c.d_zero, 0, 64));
     c.attn_part_floats = (size_t)4 << 20;
@@ -331,8 +425,11 @@ int zg_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     for (auto& kv : c.registry) (void)hipFree(kv.second.dev);
     c.registry.clear();
+    c.kv_mirrors.clear();
     (void)hipFree(c.stage);
-    (void)hipFree(c.d_flag);
+    if (c.pin) (void)hipHostFree(c.pin);
+    if (c.kv_pool) (void)hipFree(c.kv_pool);
+    (void)hipHostFree(c.d_flag);
     (void)hipFree(c.d_zero);
     (void)hipFree(c.attn_part);
     (void)hipStreamDestroy(c.own_stream);
@@ -374,6 +471,7 @@ int zg_register_tensor(const float* host_ptr, size_t len) {
 int zg_unregister_tensor(const float* host_ptr) {
     ZG_TRY(require_init());
     Ctx& c = ctx();
+    c.kv_mirrors.erase(host_ptr);  // (a KV-cache mirror keyed by this address: the next zg_attn_forward uploads the cache again)
     auto it = c.registry.find(host_ptr);
     if (it == c.registry.end()) return ZG_OK;  // never registered (or a device pointer): nothing to drop
     ZG_HIP(hipStreamSynchronize(c.stream));
@@ -388,6 +486,8 @@ int zg_unregister_all(void) {
     ZG_HIP(hipStreamSynchronize(c.stream));
     for (auto& kv : c.registry) (void)hipFree(kv.second.dev);
     c.registry.clear();
+    c.kv_mirrors.clear();
+    c.kv_pool_off = 0;  // the pool is a bump allocator: it empties when every mirror is gone
     return ZG_OK;
 }
 
@@ -409,8 +509,9 @@ int zg_linear_forward(size_t in_features, size_t out_features, const float* weig
     float* y;
     ZG_TRY(call.param(weight, in_features * out_features, &w));
     ZG_TRY(call.param(bias_or_null, out_features, &b));
-    ZG_TRY(call.in(inputs, inputs_len, &x));
-    ZG_TRY(call.out(outputs, batch * out_features, &y));
+    ZG_TRY(call.in(inputs, inputs_len, &x));  // (read by every workgroup: device memory)
+    if (in_features <= 8192) ZG_TRY(call.out_once(outputs, batch * out_features, &y));  // every element stored once
+    else ZG_TRY(call.out(outputs, batch * out_features, &y));                          // K chunks accumulate into y
     if (linear_mfma_ok(in_features, out_features, batch, call.arena_left()))
         ZG_TRY(linear_mfma(call, in_features, out_features, w, b, x, batch, y));
     else
@@ -500,11 +601,16 @@ int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len,
     const size_t* ix;
     float* out;
     ZG_TRY(call.param(weight, weight_len, &w));
-    ZG_TRY(call.in(idxs, idxs_len, &ix));
-    ZG_TRY(call.out(embeddings, idxs_len * emb_dim, &out));
+    ZG_TRY(call.in_once(idxs, idxs_len, &ix));
+    ZG_TRY(call.out_once(embeddings, idxs_len * emb_dim, &out));
     ZG_TRY(launch_embedding(w, emb_dim, ix, idxs_len, weight_len / emb_dim, out, ctx().d_flag, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
+    if (*static_cast<volatile int*>(ctx().d_flag)) {  // raised by the kernel (pinned host word), read behind the call's drain
+        *ctx().d_flag = 0;
+        set_error("embedding: index out of range (>= %zu rows)", weight_len / emb_dim);
+        return ZG_ERR_SHAPE;  // (the rows of valid indices were written, like the reference up to its bounds panic)
+    }
     return ZG_OK;
 }
 
@@ -522,7 +628,7 @@ int zg_layernorm_forward(size_t n_features, const float* weight, const float* bi
     float* x;
     ZG_TRY(call.param(weight, n_features, &g));
     ZG_TRY(call.param(bias, n_features, &b));
-    ZG_TRY(call.inout(inputs, inputs_len, &x));
+    ZG_TRY(call.inout_once(inputs, inputs_len, &x));
     ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
@@ -536,7 +642,7 @@ int zg_gelu(float* inputs, size_t inputs_len) {
     Call call;
     CallGuard guard(call);
     float* x;
-    ZG_TRY(call.inout(inputs, inputs_len, &x));
+    ZG_TRY(call.inout_once(inputs, inputs_len, &x));
     ZG_TRY(launch_gelu(x, inputs_len, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
@@ -549,7 +655,7 @@ int zg_softmax(float* inputs, size_t inputs_len) {
     Call call;
     CallGuard guard(call);
     float* x;
-    ZG_TRY(call.inout(inputs, inputs_len, &x));
+    ZG_TRY(call.inout_once(inputs, inputs_len, &x));
     ZG_TRY(launch_softmax(x, inputs_len, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
@@ -570,8 +676,8 @@ int zg_split_qkv(size_t n_embed, size_t seq_len, const float* inputs, size_t inp
     CallGuard guard(call);
     const float* in;
     float* out;
-    ZG_TRY(call.in(inputs, inputs_len, &in));
-    ZG_TRY(call.out(outputs, rows * n_embed, &out));
+    ZG_TRY(call.in_once(inputs, inputs_len, &in));
+    ZG_TRY(call.out_once(outputs, rows * n_embed, &out));
     ZG_TRY(launch_split_qkv(in, rows, n_embed, split_idx, out, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
@@ -591,8 +697,8 @@ int zg_transpose(size_t seq_len, size_t n_heads, size_t head_dim, const float* i
     CallGuard guard(call);
     const float* in;
     float* out;
-    ZG_TRY(call.in(inputs, inputs_len, &in));
-    ZG_TRY(call.out(outputs, batch * per, &out));
+    ZG_TRY(call.in_once(inputs, inputs_len, &in));
+    ZG_TRY(call.out_once(outputs, batch * per, &out));
     ZG_TRY(launch_transpose(in, batch, seq_len, n_heads, head_dim, out, call.stream()));
     ZG_TRY(call.finish());
     guard.done = true;
@@ -620,7 +726,7 @@ int zg_scaled_dot_product_attention(const float* q, size_t q_len, const float* k
     ZG_TRY(call.in(q, batch * n_heads * head_dim, &dq));
     ZG_TRY(call.in(k, k_len, &dk));
     ZG_TRY(call.in(v, k_len, &dv));
-    ZG_TRY(call.out(outputs, batch * n_heads * head_dim, &out));
+    ZG_TRY(call.out_once(outputs, batch * n_heads * head_dim, &out));
     ZG_TRY(attn_core(dq, dk, dv, (long)(n_heads * seq_len * head_dim), (long)(seq_len * head_dim), (long)head_dim,
                      batch, n_heads, seq_len, out, call.stream(), head_dim));
     ZG_TRY(call.finish());
@@ -655,27 +761,69 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     Call call;
     CallGuard guard(call);
     hipStream_t s = call.stream();
+    Ctx& c = ctx();
     const float *caw, *cab, *cpw, *cpb, *x;
-    float *kc, *vc, *out, *qkv, *q;
+    float *kc = nullptr, *vc = nullptr, *out, *qkv, *q;
     ZG_TRY(call.param(c_attn_weight, 3 * E * E, &caw));
     ZG_TRY(call.param(c_attn_bias, 3 * E, &cab));
     ZG_TRY(call.param(c_proj_weight, E * E, &cpw));
     ZG_TRY(call.param(c_proj_bias, E, &cpb));
     ZG_TRY(call.in(inputs, E, &x));
-    // Host caches: rows 0..T-2 go up, row T-1 comes back (the caller owns the cache, ops.zig:152,157).
-    const bool k_host = !is_device_ptr(k_cache), v_host = !is_device_ptr(v_cache);
-    ZG_TRY(call.inout(k_cache, seq_len * E, &kc));
-    ZG_TRY(call.inout(v_cache, seq_len * E, &vc));
-    ZG_TRY(call.out(outputs, E, &out));
-    ZG_TRY(call.out(_qkv, 3 * E, &qkv));
+    // The caller owns the caches and appends one row per call (ops.zig:152,157); what it can observe afterwards is row T-1.
+    // Host caches are mirrored on the device, keyed by their address: when this call continues the sequence the mirror holds
+    // (same pointer, same width, seq_len = rows held + 1) nothing goes up and only the new row comes back; anything else
+    // — a first sight, a restart, a jump — uploads rows 0 .. T-2 again.  A caller that EDITS earlier rows in place between two
+    // consecutive positions must drop the mirror (zg_unregister_tensor(cache)).  No room in the pool: the whole cache is staged.
+    KvMirror* mir[2] = {nullptr, nullptr};
+    float* host_cache[2] = {k_cache, v_cache};
+    float** dev_cache[2] = {&kc, &vc};
+    for (int i = 0; i < 2; ++i) {
+        if (is_device_ptr(host_cache[i])) {
+            *dev_cache[i] = host_cache[i];
+            continue;
+        }
+        KvMirror* m = nullptr;
+        auto it = c.kv_mirrors.find(host_cache[i]);
+        if (it != c.kv_mirrors.end()) m = &it->second;
+        const size_t need = seq_len * E;
+        if (m == nullptr || m->cap_floats < need) {  // a slot for this cache: the reference's context (1024 rows) or twice what is needed
+            const size_t cap = std::max(need * 2, (size_t)1024 * E);
+            const size_t off = (c.kv_pool_off + 255) & ~(size_t)255;
+            if (c.kv_pool != nullptr && off + cap * sizeof(float) <= c.kv_pool_cap) {
+                KvMirror fresh;
+                fresh.dev = reinterpret_cast<float*>(c.kv_pool + off);
+                fresh.cap_floats = cap;
+                fresh.n_embed = E;
+                fresh.rows = 0;
+                c.kv_pool_off = off + cap * sizeof(float);
+                m = &(c.kv_mirrors[host_cache[i]] = fresh);  // (an outgrown slot stays behind until zg_unregister_all)
+            } else {
+                m = nullptr;
+                c.kv_mirrors.erase(host_cache[i]);
+            }
+        }
+        if (m == nullptr) {  // pool exhausted: rows 0..T-2 go up, row T-1 comes back, every call
+            ZG_TRY(call.inout(host_cache[i], seq_len * E, dev_cache[i]));
+            continue;
+        }
+        if (m->n_embed != E || m->rows + 1 != seq_len) {
+            if (seq_len > 1) ZG_HIP(hipMemcpyAsync(m->dev, host_cache[i], (seq_len - 1) * E * sizeof(float), hipMemcpyHostToDevice, s));
+            m->n_embed = E;
+        }
+        m->rows = 0;  // (valid again once this call has succeeded)
+        mir[i] = m;
+        *dev_cache[i] = m->dev;
+    }
+    ZG_TRY(call.out_once(outputs, E, &out));  // stored once by c_proj
+    ZG_TRY(call.out(_qkv, 3 * E, &qkv));      // read back by the append and the attention: device memory
     ZG_TRY(call.out(_q, E, &q));
-    (void)k_host;
-    (void)v_host;
     // c_attn (ops.zig:143)
     ZG_TRY(linear_device(E, 3 * E, caw, cab, x, 1, qkv, s));
-    // cache append (ops.zig:151-152, :156-157)
+    // cache append (ops.zig:151-152, :156-157): into the device cache, and — for mirrored host caches — row T-1 back to the caller
     ZG_TRY(launch_copy_f32(qkv + E, kc + (seq_len - 1) * E, E, s));
     ZG_TRY(launch_copy_f32(qkv + 2 * E, vc + (seq_len - 1) * E, E, s));
+    if (mir[0]) ZG_TRY(call.also_out(k_cache + (seq_len - 1) * E, qkv + E, E * sizeof(float)));
+    if (mir[1]) ZG_TRY(call.also_out(v_cache + (seq_len - 1) * E, qkv + 2 * E, E * sizeof(float)));
     // attention straight over the [T, H, hd] cache (replaces transposes + sdpa, ops.zig:153-171);
     // the merged heads land in _q like the reference's "untranspose" (ops.zig:171)
     ZG_TRY(attn_core(qkv, kc, vc, 0, (long)hd, (long)E, 1, n_heads, seq_len, q, s, hd));
@@ -683,6 +831,8 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     ZG_TRY(linear_device(E, E, cpw, cpb, q, 1, out, s));
     ZG_TRY(call.finish());
     guard.done = true;
+    for (KvMirror* m : mir)
+        if (m) m->rows = seq_len;
     return ZG_OK;
 }
 

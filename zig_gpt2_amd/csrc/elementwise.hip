@@ -29,7 +29,9 @@ __device__ __forceinline__ float block_allmax(float v, float* s_red) {
     return t;
 }
 
-// LayerNorm.forward (src/ops.zig:82-104): one wave per row, in place.
+// LayerNorm.forward (src/ops.zig:82-104): one wave per row, in place.  Rows of up to 64 x 32 elements are held in registers
+// between the statistics and the normalisation: every element is read once and written once (the op tier hands small host
+// buffers over in place, across PCIe).
 __global__ __launch_bounds__(256) void layernorm_kernel(float* x, int rows, int n, const float* g,
                                                         const float* b, float eps) {
     const int lane = threadIdx.x & 63;
@@ -37,6 +39,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* x, int rows, int 
     if (row >= rows) return;
     float* r = x + (size_t)row * n;
     float s1 = 0.0f, s2 = 0.0f;
+    if (n <= 64 * 32) {
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int i = lane + 64 * j;
+            v[j] = i < n ? r[i] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            s1 += v[j];
+            s2 = fmaf(v[j], v[j], s2);
+        }
+        s1 = wave_allsum(s1);
+        s2 = wave_allsum(s2);
+        const float mean = s1 / (float)n;
+        const float std_ = sqrtf(s2 / (float)n - mean * mean + eps);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int i = lane + 64 * j;
+            if (i < n) r[i] = (v[j] - mean) / std_ * g[i] + b[i];
+        }
+        return;
+    }
     for (int i = lane; i < n; i += 64) {
         const float v = r[i];
         s1 += v;
@@ -63,9 +88,35 @@ __global__ __launch_bounds__(256) void gelu_kernel(float* x, size_t n) {
         x[i] = gelu_ref(x[i]);
 }
 
-// softmax (src/ops.zig:231-241): the whole slice is one vector; single workgroup, in place.
+// softmax (src/ops.zig:231-241): the whole slice is one vector; single workgroup, in place.  Up to 1024 x 64 elements (the
+// logits of every GPT-2 vocabulary, src/main.zig:203) stay in registers across the three passes: read once, written once.
 __global__ __launch_bounds__(1024) void softmax_kernel(float* x, size_t n) {
     __shared__ float s_red[16];
+    if (n <= (size_t)1024 * 64) {
+        float v[64];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const size_t i = threadIdx.x + (size_t)1024 * j;
+            v[j] = i < n ? x[i] : -3.0e38f;
+            mx = fmaxf(mx, v[j]);
+        }
+        mx = block_allmax(mx, s_red);
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const size_t i = threadIdx.x + (size_t)1024 * j;
+            v[j] = i < n ? __expf(v[j] - mx) : 0.0f;
+            sum += v[j];
+        }
+        sum = block_allsum(sum, s_red);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const size_t i = threadIdx.x + (size_t)1024 * j;
+            if (i < n) x[i] = v[j] / sum;
+        }
+        return;
+    }
     float mx = -3.0e38f;
     for (size_t i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, x[i]);
     mx = block_allmax(mx, s_red);
@@ -363,6 +414,19 @@ int launch_softmax(float* x, size_t n, hipStream_t s) {
     return ZG_OK;
 }
 
+// The completion word of an op-tier call: the host polls this pinned word instead of paying hipStreamSynchronize's wake-up
+// (tools/microbench/sync_cost.hip: 9.6-11.0 against 12.0-13.3 us per one-kernel call).  In stream order behind the call's
+// kernels, whose results the kernel boundary has already released to the system.
+__global__ void done_flag_kernel(unsigned* flag, unsigned seq) {
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int launch_done_flag(unsigned* flag, unsigned seq, hipStream_t s) {
+    hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, s, flag, seq);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 __global__ void epoch_bump_kernel(unsigned* epoch) { *epoch += 1u; }
 int launch_epoch_bump(unsigned* epoch, hipStream_t s) {
     hipLaunchKernelGGL(epoch_bump_kernel, dim3(1), dim3(1), 0, s, epoch);
@@ -373,16 +437,9 @@ int launch_epoch_bump(unsigned* epoch, hipStream_t s) {
 int launch_embedding(const float* w, size_t emb_dim, const size_t* idx, size_t n_idx, size_t n_rows,
                      float* out, int* d_oob, hipStream_t s) {
     if (n_idx == 0) return ZG_OK;
+    // (d_oob is a pinned host word: the caller reads it behind its own drain of the stream)
     hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)n_idx), dim3(256), 0, s, w, emb_dim, idx, n_rows, out, d_oob);
     ZG_HIP(hipGetLastError());
-    int oob = 0;
-    ZG_HIP(hipMemcpyAsync(&oob, d_oob, sizeof(int), hipMemcpyDeviceToHost, s));
-    ZG_HIP(hipStreamSynchronize(s));
-    if (oob) {
-        ZG_HIP(hipMemsetAsync(d_oob, 0, sizeof(int), s));
-        zg::set_error("embedding: index out of range (>= %zu rows)", n_rows);
-        return ZG_ERR_SHAPE;
-    }
     return ZG_OK;
 }
 

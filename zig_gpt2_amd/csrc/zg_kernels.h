@@ -152,6 +152,7 @@ int launch_epoch_bump(unsigned* epoch, hipStream_t s);  // measurement chains: a
 int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s);
 int launch_gelu(float* x, size_t n, hipStream_t s);
 int launch_softmax(float* x, size_t n, hipStream_t s);
+int launch_done_flag(unsigned* flag, unsigned seq, hipStream_t s);
 int launch_embedding(const float* w, size_t emb_dim, const size_t* idx, size_t n_idx, size_t n_rows,
                      float* out, int* d_oob_flag, hipStream_t s);
 int launch_split_qkv(const float* in, size_t rows, size_t n_embed, size_t split_idx, float* out, hipStream_t s);

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <array>
 #include <stdexcept>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -213,9 +214,15 @@ struct GPT {
 };
 
 // ---------------------------------------------------------------- src/main.zig:322-342 (greedy)
-static std::vector<size_t> generate(GPT& gpt, const std::vector<size_t>& inputs, size_t n_steps, State& state) {
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// (t64: seconds spent on the first 64 positions — BASELINE configs[0]'s window — when the run is at least that long)
+static std::vector<size_t> generate(GPT& gpt, const std::vector<size_t>& inputs, size_t n_steps, State& state, double* t64 = nullptr) {
     std::vector<size_t> out;
     size_t token = 0;
+    const double t0 = now_s();
     for (size_t s = 0; s < n_steps; ++s) {
         if (s < inputs.size()) {
             token = inputs[s];
@@ -224,6 +231,7 @@ static std::vector<size_t> generate(GPT& gpt, const std::vector<size_t>& inputs,
             token = gpt.sample_greedy(s + 1, token, state);
         }
         out.push_back(token);
+        if (s + 1 == 64 && t64) *t64 = now_s() - t0;
     }
     return out;
 }
@@ -485,13 +493,21 @@ int main(int argc, char** argv) {
         ops::check(zg_init(0));
         const Weights w = from_dir ? Weights(config, wsrc) : Weights(config, seed);
         std::vector<size_t> out;
+        double t64 = 0.0, t_all = 0.0;
         if (model_tier) {
+            const double t0 = now_s();
             out = generate_model_tier(config, w, inputs, n_steps);
+            t_all = now_s() - t0;  // (handle creation, graph capture and weight upload included: one call does it all here)
         } else {
             State state(config);
             GPT gpt(config, w);
-            out = generate(gpt, inputs, n_steps, state);
+            const double t0 = now_s();
+            out = generate(gpt, inputs, n_steps, state, &t64);
+            t_all = now_s() - t0;
         }
+        // timing on stderr (stdout carries the tokens): what an unchanged main.zig over this ops.zig would see
+        fprintf(stderr, "{\"tier\": \"%s\", \"model\": \"%s\", \"steps\": %zu, \"seconds\": %.4f, \"tokens_per_s\": %.1f, \"first_64_tokens_per_s\": %.1f}\n",
+                model_tier ? "model" : "op", name.c_str(), n_steps, t_all, t_all > 0 ? n_steps / t_all : 0.0, t64 > 0 ? 64.0 / t64 : 0.0);
         for (size_t i = 0; i < out.size(); ++i) printf("%zu%s", out[i], i + 1 < out.size() ? " " : "\n");
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
