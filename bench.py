@@ -78,8 +78,29 @@ def self_launch(a):
     sys.exit(0)
 
 
+def scaling_fields(dist, torch, device, world, value, ref_value, own_rate, bcast_ms, bcast_bytes):
+    """What makes an N > 1 line self-contained: the one-GPU figure with the SAME per-GPU work (rank 0 alone, timed before the
+    collective region), the efficiency it implies, the spread over the ranks, and the rate of the one collective."""
+    lo = torch.tensor([own_rate], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    ref = torch.tensor([ref_value if ref_value else 0.0], dtype=torch.float64, device=device)
+    dist.broadcast(ref, src=0)
+    ref_value = float(ref.item())
+    return {
+        "scaling_reference": {"n_gpus": 1, "value": round(ref_value, 1), "unit": "tokens/s",
+                              "how": "rank 0 alone, one generation of its per-GPU load after one warm-up generation, the other ranks "
+                                     "waiting at a barrier; same handle, same prompts as in the timed region"},
+        "scaling_efficiency": round(value / (world * ref_value), 4) if ref_value > 0 else None,
+        "per_rank_tokens_per_s": {"min": round(float(lo.item()), 1), "max": round(float(hi.item()), 1)},
+        "weight_broadcast_GBps": round(bcast_bytes / bcast_ms / 1e6, 2) if bcast_ms and bcast_ms > 0 else None,
+    }
+
+
 def dry_run(a, rank, world):
-    """The N-rank control flow of main() on CPU: same sharding helpers, same collectives, gloo instead of RCCL."""
+    """The N-rank control flow of main() on CPU: same sharding helpers, same collectives, same line (the scaling fields
+    included), gloo instead of RCCL; a "generation" is a fixed amount of numpy arithmetic."""
     import torch
     import torch.distributed as dist
 
@@ -90,6 +111,7 @@ def dry_run(a, rank, world):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = synth.CONFIGS["tiny"]
     ppg = a.prompts_per_gpu or (1 if world == 1 else 8)
+    ctx = a.ctx or cfg.context_size
     n = 1 << 20
     arena = torch.full((n,), 7, dtype=torch.uint8) if rank == 0 else torch.zeros(n, dtype=torch.uint8)
     dist.barrier()
@@ -99,16 +121,41 @@ def dry_run(a, rank, world):
     assert int(arena[-1]) == 7
     mine = shard.shard_prompts(ppg * world, world, rank)
     assert len(mine) == ppg
+    work = np.ones((64, 64))
+
+    def one_generation():
+        x = work
+        for _ in range(40):
+            x = x @ work * 1e-2
+        return x
+
+    ref_value = None
+    if rank == 0:  # the one-GPU reference: rank 0 alone
+        one_generation()
+        t = time.perf_counter()
+        one_generation()
+        ref_value = ppg * (ctx - 1) / (time.perf_counter() - t)
     dist.barrier()
-    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    for _ in range(a.warmup):
+        one_generation()
+    dist.barrier()
+    t_wall = time.perf_counter()
+    for _ in range(a.steps):
+        one_generation()
+    own_s = time.perf_counter() - t_wall
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t_wall], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    value = world * ppg * (ctx - 1) * a.steps / elapsed
+    extra = scaling_fields(dist, torch, torch.device("cpu"), world, value, ref_value, ppg * (ctx - 1) * a.steps / own_s, bcast_ms, n)
     if rank == 0:
-        print(json.dumps({"metric": "tokens/sec GPT-2-124M greedy 1024-ctx", "value": 0.0, "unit": "tokens/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dry_run": True, "data": "none (CPU rehearsal of the launch path)",
+        print(json.dumps({"metric": "tokens/sec GPT-2-124M greedy 1024-ctx", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dry_run": True, "data": "none (CPU rehearsal of the launch path: a generation is numpy arithmetic)",
                           "config": {"workload": f"dry run, {ppg} prompt(s)/rank x {world} rank(s), model {cfg.n_embed}-wide",
                                      "prompts_per_gpu": ppg, "global_prompts": ppg * world},
-                          "weight_broadcast_ms": round(bcast_ms, 3), "max_over_ranks_s": float(t.item())}), flush=True)
+                          "weight_broadcast_ms": round(bcast_ms, 3), "max_over_ranks_s": elapsed, **extra}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -401,10 +448,21 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
+    class NativeDistError(RuntimeError):
+        pass
+
     native_ok = False
     try:
+        # zg_dist_init is a rendezvous (ncclCommInitRank): every rank enters it or none does.  So the ranks first agree that
+        # RCCL can be bound everywhere (zg_dist_available is not a collective), and only rank 0's id failing is left to ship.
+        ok, err = True, None
+        try:
+            _lib.check(lib.zg_dist_available())
+        except _lib.ZgError as e:
+            ok, err = False, str(e)
+        if not all_ranks_ok(ok):
+            raise NativeDistError(err or "RCCL cannot be bound on another rank")
         uid = (C.c_ubyte * 128)()
-        err = None
         if rank == 0:
             try:
                 _lib.check(lib.zg_dist_unique_id(uid, 128))
@@ -417,14 +475,13 @@ def main():
             if err is None:
                 uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
         if err is not None:
-            raise _lib.ZgError(err)
-        ok = True
+            raise NativeDistError(err)
         try:
             _lib.check(lib.zg_dist_init(uid, 128, rank, world))
         except _lib.ZgError as e:
             ok, err = False, str(e)
         if not all_ranks_ok(ok):
-            raise _lib.ZgError(err or "zg_dist_init failed on another rank")
+            raise NativeDistError(err or "zg_dist_init failed on another rank")
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -434,11 +491,12 @@ def main():
         except _lib.ZgError as e:
             ok, err = False, str(e)
         if not all_ranks_ok(ok):
-            raise _lib.ZgError(err or "zg_gpt_broadcast_weights failed on another rank")
+            raise NativeDistError(err or "zg_gpt_broadcast_weights failed on another rank")
         bcast_ms = float(ms.value)
         _lib.check(lib.zg_dist_finalize())
         native_ok = True
-    except _lib.ZgError as e:
+    except (NativeDistError, _lib.ZgError) as e:
+        lib.zg_dist_finalize()  # a communicator made before the failure must not outlive it (no-op without one)
         bcast_note = f"native RCCL path unavailable ({e})"  # (a one-GPU box without librccl: nothing to broadcast to)
     finally:
         C.CDLL(None).fflush(None)
@@ -471,6 +529,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # N > 1: the one-GPU figure with the same per-GPU work, taken by rank 0 alone before the collective region
+    ref_value = None
+    if dist is not None:
+        if rank == 0:
+            one_generation()
+            torch.cuda.synchronize()
+            t_ref = time.perf_counter()
+            one_generation()
+            torch.cuda.synchronize()
+            ref_value = ppg * (ctx - 1) / (time.perf_counter() - t_ref)
+        dist.barrier()
     for _ in range(a.warmup):
         one_generation()
     sync_all()
@@ -480,6 +549,8 @@ def main():
     for _ in range(a.steps):
         one_generation()
     e1.record(stream)
+    torch.cuda.synchronize()
+    own_s = time.perf_counter() - t_wall  # this rank's own K generations (before it waits for the others)
     sync_all()
     wall_s = time.perf_counter() - t_wall
     dev_s = e0.elapsed_time(e1) / 1e3
@@ -495,6 +566,11 @@ def main():
     gen_tokens = ppg * (ctx - 1)
     value = world * gen_tokens * a.steps / elapsed
 
+    scaling_extra = {}
+    if dist is not None:
+        _, wbytes_region = model.weight_arena()
+        scaling_extra = scaling_fields(dist, torch, torch.device("cuda", local_rank), world, value, ref_value,
+                                       gen_tokens * a.steps / own_s, bcast_ms, wbytes_region)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -648,6 +724,7 @@ def main():
         "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 3),
         "weight_broadcast": bcast_note or "zg_gpt_broadcast_weights: one ncclBroadcast of the arena's weight region on the library's stream (device time, HIP events)",
         "first_tokens": [int(t) for t in ids[0, :8]],
+        **scaling_extra,
     }
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, weights, prompts[0], a.cpu_seconds)

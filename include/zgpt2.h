@@ -251,6 +251,9 @@ int zg_gpt_weight_arena(zg_gpt* g, void** device_ptr, size_t* bytes);
  * generates its own prompts.  zg_dist_allgather collects equal-sized device buffers (the ranks' token matrices) in rank
  * order.  RCCL is bound at run time: on a box without librccl.so these return ZG_ERR_UNSUPPORTED, everything else works. */
 #define ZG_DIST_ID_BYTES 128
+/* Not a collective: ZG_OK when RCCL can be bound in this process.  zg_dist_init is a rendezvous — every rank must enter it or
+ * none — so a launcher lets its ranks agree on this answer first (bench.py does, over torch.distributed). */
+int zg_dist_available(void);
 int zg_dist_unique_id(void* id_out, size_t id_bytes);
 int zg_dist_init(const void* id, size_t id_bytes, int rank, int world_size);
 int zg_dist_world(int* rank, int* world_size); /* world_size 0: no communicator */
@@ -325,7 +328,7 @@ int zg_gpt_generate_fetch_many(zg_gpt* const* handles, size_t n_handles, size_t 
  * boundary included) and the kernel's algorithmic weight bytes.  A warm-cache microbenchmark: the
  * in-situ numbers are zg_gpt_profile_step's.  Options ride in the upper bits of the class argument: ZG_TIME_WALK_LAYERS walks
  * the layers (launch i takes layer i mod n_layer, so that no launch finds its weights in the L2s: the memory-side cost of the
- * real step), ZG_TIME_AT(t) runs the chain at sequence length t. */
+ * real step), ZG_TIME_AT(t) runs the chain at sequence length t (t < 32768: the option field is 15 bits wide). */
 #define ZG_TIME_WALK_LAYERS 0x100
 #define ZG_TIME_AT(t) ((int)((unsigned)(t) << 16))
 int zg_gpt_time_kernel(zg_gpt* g, int which_and_options, int iters, float* avg_us, size_t* algorithmic_bytes);

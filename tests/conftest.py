@@ -10,6 +10,17 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fuzz: the long form of the seeded sweeps (minutes; run with -m fuzz, skipped otherwise)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # the long sweeps carry both markers: `-m gpu` (the round-end suite) must not drag them in; only an expression naming `fuzz` does
+    if "fuzz" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="long sweep: run with -m fuzz")
+    for it in items:
+        if "fuzz" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

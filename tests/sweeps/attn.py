@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Random cases of tests/test_attn_prefill_gpu.py::test_attn_prefill_matches_float64 (batch, prompt length, heads, forced key
-tiles per workgroup, cache / qkv rows as the K / V source, a dominant key): python tools/fuzz_attn.py [first_seed] [count]."""
+tiles per workgroup, cache / qkv rows as the K / V source, a dominant key): python tests/sweeps/attn.py [first_seed] [count]."""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 from zig_gpt2_amd import _lib
@@ -23,3 +23,4 @@ for seed in range(first, first + count):
         bad.append((seed, case))
         traceback.print_exc(limit=1)
 print(f"{count} cases from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Random byte strings (all 256 byte values, long runs, NULs, words beyond the reference's 20-byte buffer, partial vocabularies)
 through the C-ABI tokenizer against the Python restatement of src/bpe.zig: same ids or the same refusal, no crash.  CPU only.
-python tools/fuzz_bpe.py [first_seed] [count]"""
+python tests/sweeps/bpe.py [first_seed] [count]"""
 import os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 from oracle import bpe_oracle
@@ -44,3 +44,4 @@ for seed in range(first, first + count):
             bad.append((seed, "decode raised", e))
     enc.close()
 print(f"{count} texts from seed {first}: {len(bad)} mismatches {bad[:5]}")
+sys.exit(1 if bad else 0)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Edge and nonsense arguments through the op tier of the C ABI: zero lengths, zero dimensions, lengths that do not divide,
 null pointers, a sequence length of 0, head counts that do not divide — every call must RETURN (ZG_OK or an error code with a
-message), never crash or hang, and the library must keep working afterwards.  python tools/fuzz_errors.py [seed] [count]"""
+message), never crash or hang, and the library must keep working afterwards.  python tests/sweeps/errors.py [seed] [count]"""
 import ctypes as C, os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
 import numpy as np
 from zig_gpt2_amd import _lib, ops, synth
@@ -21,6 +21,7 @@ def size():
 def ptr(i):
     return None if rng.integers(0, 12) == 0 else P(buf[i])
 codes = {}
+hip_errors = []  # a nonsense argument must be refused by a check, not by the HIP runtime
 only = int(os.environ.get("ONLY", "-1"))
 for it in range(count):
     k = int(rng.integers(0, 12))
@@ -61,8 +62,12 @@ for it in range(count):
     else: r = zg.zg_softmax(ptr(0), size())
     codes[r] = codes.get(r, 0) + 1
     if r != 0: assert len(zg.zg_last_error()) > 0
+    if r == -3:
+        hip_errors.append((it, k))
+        print(f"call {it} kind {k}: HIP error: {zg.zg_last_error().decode(errors='replace')}", flush=True)
 # the library still computes
 w = synth.fill_normal(1, 64 * 32, 0, 0.1).reshape(32, 64); x = synth.fill_normal(2, 64, 0, 1.0); y = np.zeros(32, np.float32)
 ops.Linear(64, 32, w, None).forward(x, y)
 assert np.abs(y - w @ x).max() < 1e-5
 print(f"{count} calls returned; status histogram {dict(sorted(codes.items()))}; the library still computes")
+sys.exit(1 if hip_errors else 0)

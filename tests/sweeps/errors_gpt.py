@@ -2,9 +2,9 @@
 """Edge and nonsense arguments through the MODEL tier of the C ABI: configurations that cannot be built, sequence lengths 0 and
 beyond the context, token ids beyond the vocabulary, wrong token counts, NULL arrays, zero steps, prompts longer than the run —
 every call must RETURN a status (no crash, no hang), and a good call on the same handle must still match the oracle afterwards.
-python tools/fuzz_errors_gpt.py [seed] [count]"""
+python tests/sweeps/errors_gpt.py [seed] [count]"""
 import ctypes as C, os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
 import numpy as np
 import oracle

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Random shapes through zg_gemm_bf16_nt (C = A B^T + bias, optional GELU, bf16 or fp32 out) against float64: any M, ragged N,
-K a multiple of 64 from 128 up (both persistent kernels: beyond 16320 the eight-wave one).  python tools/fuzz_gemm.py [first_seed] [count]"""
+K a multiple of 64 from 128 up (both persistent kernels: beyond 16320 the eight-wave one).  python tests/sweeps/gemm.py [first_seed] [count]"""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
 import numpy as np
 import torch
@@ -44,3 +44,4 @@ for seed in range(first, first + count):
         print(what)
         traceback.print_exc(limit=1)
 print(f"{count} shapes from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

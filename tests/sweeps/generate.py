@@ -2,9 +2,9 @@
 """Random generate() configurations against the oracle's greedy loop: model, batch, ragged prompt lengths, steps, KV cache type
 (fp32 / 24-bit: ids must match; fp16 is outside the bound and not swept), weight type, graph on / off, whole-prompt pass on / off,
 L2 prefetcher on / off.  A differing id is accepted only at a numerical tie of the oracle's own top two logits (golden_io).
-python tools/fuzz_generate.py [first_seed] [count] [max_steps = 96]"""
+python tests/sweeps/generate.py [first_seed] [count] [max_steps = 96]"""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
 import numpy as np
 import oracle
@@ -48,3 +48,4 @@ for seed in range(first, first + count):
         print(what)
         traceback.print_exc(limit=2)
 print(f"{count} configurations from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

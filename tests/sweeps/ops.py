@@ -2,9 +2,9 @@
 """Random shapes through the op tier against float64 numpy and the oracle: Linear.forward (any in_features incl. > 8192, ragged out_features,
 batch 1..40: GEMV kernels, K chunks, the matrix-core path from batch 16), LayerNorm, gelu, softmax, incremental CausalSelfAttention.forward,
 scaled_dot_product_attention, split_qkv / transpose, Embedding.
-python tools/fuzz_ops.py [first_seed] [count]"""
+python tests/sweeps/ops.py [first_seed] [count]"""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'oracle'))
 import numpy as np
 import oracle
@@ -124,3 +124,4 @@ for seed in range(first, first + count):
         bad.append(seed)
         traceback.print_exc(limit=1)
 print(f"{count} cases from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

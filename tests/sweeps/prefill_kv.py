@@ -2,9 +2,9 @@
 """The whole-prompt pass with the narrow KV caches (24-bit: inside the parity bound; fp16: outside, opt-in) over random models,
 batches and prompt lengths: the decode steps ON TOP of the prefilled cache against the oracle at 1e-3 / 1e-2 of the logit scale —
 what the c_attn epilogue's cache append (fp32 -> 24-bit / fp16, every GEMM family) and the attention's cache reads must agree on.
-python tools/fuzz_prefill_kv.py [first_seed] [count]"""
+python tests/sweeps/prefill_kv.py [first_seed] [count]"""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
 import numpy as np
 import oracle
@@ -47,3 +47,4 @@ for seed in range(first, first + count):
         print(what)
         traceback.print_exc(limit=1)
 print(f"{count} cases from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

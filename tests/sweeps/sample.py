@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """GPT.sample (src/main.zig:198-207: forward, logits / temp, softmax, an index drawn against the running sum) over random models,
 batches, temperatures and uniforms against the oracle: probabilities agree, the pick is the oracle's except where u * total
-lands within 1e-6 of a boundary of the running sum; both sides are fed the device's picks.  python tools/fuzz_sample.py [first_seed] [count]"""
+lands within 1e-6 of a boundary of the running sum; both sides are fed the device's picks.  python tests/sweeps/sample.py [first_seed] [count]"""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
 import numpy as np
 import oracle
@@ -47,3 +47,4 @@ for seed in range(first, first + count):
         print(what)
         traceback.print_exc(limit=1)
 print(f"{count} runs from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

@@ -2,9 +2,9 @@
 """Stateful fuzz of ONE model handle: a random sequence of generate() calls, token-at-a-time forward loops and whole-prompt passes
 followed by decode steps — different prompt lengths, rows, step counts, each starting a new sequence on the same handle (graphs
 per 64-position bucket, epochs of the tagged hand-overs, the side-stream prefetcher and the caches all carry state between calls) —
-every result against a fresh oracle.  python tools/fuzz_session.py [first_seed] [count]"""
+every result against a fresh oracle.  python tests/sweeps/session.py [first_seed] [count]"""
 import os, sys, traceback
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
 import numpy as np
 import oracle
@@ -68,3 +68,4 @@ for seed in range(first, first + count):
         traceback.print_exc(limit=2)
     m.close()
 print(f"{count} sessions from seed {first}: {len(bad)} failed {bad}")
+sys.exit(1 if bad else 0)

@@ -27,6 +27,14 @@ def test_gpus_2_launches_two_ranks_by_itself():
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["scaling"] == "weak"
     assert d["weight_broadcast_ms"] is not None and d["weight_broadcast_ms"] >= 0
     assert d["config"]["global_prompts"] == 16 and d["config"]["prompts_per_gpu"] == 8  # BASELINE configs[2]: 8 per GPU
+    # the N > 1 line is self-contained: the one-GPU figure with the same per-GPU work, the efficiency it implies, the spread
+    ref = d["scaling_reference"]
+    assert ref["n_gpus"] == 1 and ref["value"] > 0
+    assert abs(d["scaling_efficiency"] - d["value"] / (2 * ref["value"])) < 1e-3
+    pr = d["per_rank_tokens_per_s"]
+    assert 0 < pr["min"] <= pr["max"]
+    assert d["value"] <= 2 * pr["max"] * 1.001  # the job is as slow as its slowest rank
+    assert d["weight_broadcast_GBps"] is not None and d["weight_broadcast_GBps"] > 0
 
 
 def test_rank_count_must_match_gpus():

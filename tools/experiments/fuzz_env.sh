@@ -8,7 +8,7 @@ for i in $(seq 1 ${2:-16}); do
   envs="ZGPT2_DECODE_PATHS_OFF=$off ZGPT2_GRAPH_STEPS=$gs"
   [ $wgs -gt 0 ] && envs="$envs ZGPT2_GEMM_WGS=$wgs"
   [ $pf -lt 2 ] && envs="$envs ZGPT2_PREFETCH=$pf"
-  r1=$(env $envs python tools/fuzz_generate.py $(( 30000 + i * 50 )) 30 2>&1 | tail -1)
-  r2=$(env $envs python tools/fuzz_session.py $(( 30000 + i * 50 )) 20 2>&1 | tail -1)
+  r1=$(env $envs python tests/sweeps/generate.py $(( 30000 + i * 50 )) 30 2>&1 | tail -1)
+  r2=$(env $envs python tests/sweeps/session.py $(( 30000 + i * 50 )) 20 2>&1 | tail -1)
   echo "$envs | $r1 | $r2"
 done

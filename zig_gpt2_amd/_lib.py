@@ -75,6 +75,7 @@ SIGNATURES = {
     "zg_gpt_load_block_tensor": (C.c_int, [vp, sz, C.c_int, vp, sz]),
     "zg_gpt_load_tensor": (C.c_int, [vp, C.c_int, vp, sz]),
     "zg_gpt_weight_arena": (C.c_int, [vp, C.POINTER(vp), szp]),
+    "zg_dist_available": (C.c_int, []),
     "zg_dist_unique_id": (C.c_int, [vp, sz]),
     "zg_dist_init": (C.c_int, [vp, sz, C.c_int, C.c_int]),
     "zg_dist_world": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -569,6 +569,7 @@ int enqueue_prefill(zg_gpt* g, size_t P, bool last_block_full, hipStream_t s) {
             qa.sk_ws = g->pf_ws;
             qa.sk_ws_bytes = g->pf_ws_floats * 4;
             qa.sk_flags = g->sk_flags;
+            qa.sk_flags_words = 512;  // (carve: 2048 bytes)
             qa.sk_epoch = ++g->sk_epoch;
             g->sk_used = true;
         }
@@ -1554,7 +1555,8 @@ int zg_gpt_time_kernel(zg_gpt* g, int which_and_options, int iters, float* avg_u
     const int which = which_and_options & 0xff;
     const bool cycle = (which_and_options & ZG_TIME_WALK_LAYERS) != 0;  // walk the layers, so that no launch finds its weights in the L2s
     const size_t t_opt = (size_t)((unsigned)which_and_options >> 16);    // another position for the attention kernel (0: mid-context)
-    ZG_REQUIRE(g && avg_us && iters > 0 && which_and_options >= 0 && which <= 6, ZG_ERR_ARG, "time_kernel: bad argument");
+    // (ZG_TIME_AT(t) occupies bits 16..30: t up to 32767 — every GPT-2 context; a larger t would set the sign bit)
+    ZG_REQUIRE(g && avg_us && iters > 0 && which_and_options >= 0 && which <= 6, ZG_ERR_ARG, "time_kernel: bad argument (ZG_TIME_AT takes t < 32768)");
     hipStream_t s = gs(g);
     ZG_REQUIRE(s != nullptr, ZG_ERR_UNSUPPORTED, "time_kernel needs a capturable stream");
     const size_t E = g->cfg.n_embed, wb = g->wbytes;

@@ -329,6 +329,7 @@ static int linear_device_wide(Call& call, size_t in_f, size_t out_f, const float
 static int attn_core(const float* q, const float* k, const float* v, long stride_b, long stride_h,
                      long stride_t, size_t batch, size_t n_heads, size_t seq_len, float* out, hipStream_t s, size_t head_dim = 64) {
     Ctx& c = ctx();
+    if (batch == 0 || n_heads == 0) return ZG_OK;  // k.len below one sequence: the reference's loop over the batch does nothing (ops.zig:259-261)
     const int splits = (int)((seq_len + kAttnChunk - 1) / kAttnChunk);
     // (a shape whose split partials do not fit the op tier's buffer — very long sequences x many heads — takes the general kernel too)
     if (head_dim != 64 || batch * n_heads * splits * kPartStride > c.attn_part_floats)
@@ -554,7 +555,7 @@ int zg_debug_attn_prefill(const float* qkv, uint16_t* out, size_t batch, size_t 
     ZG_REQUIRE(qkv && out && is_device_ptr(qkv) && is_device_ptr(out) && (!k_cache || (v_cache && is_device_ptr(k_cache) && is_device_ptr(v_cache))) &&
                    (!ws || is_device_ptr(ws)),
                ZG_ERR_ARG, "debug_attn_prefill: device pointers");
-    ZG_REQUIRE(batch >= 1 && n_tokens >= 1 && batch * n_tokens < (1u << 24) && n_embed < (1u << 16) && (!k_cache || ctx_len >= n_tokens) &&
+    ZG_REQUIRE(batch >= 1 && n_tokens >= 1 && n_heads >= 1 && n_embed == 64 * n_heads && batch * n_tokens < (1u << 24) && n_embed < (1u << 16) && (!k_cache || ctx_len >= n_tokens) &&
                    key_tiles >= 0 && key_tiles <= 255,
                ZG_ERR_ARG, "debug_attn_prefill: arguments");
     return launch_attn_prefill(qkv, out, (int)batch, (int)n_tokens, (int)n_embed, (int)n_heads, ws, ws_floats, k_cache, v_cache, (int)ctx_len, ctx().stream,

@@ -641,10 +641,15 @@ __global__ __launch_bounds__(256) void attn_any_dim_kernel(const float* __restri
 
 int launch_attn_any_dim(const float* q, const float* k, const float* v, long stride_b, long stride_h, long stride_t, int batch, int n_heads,
                         int head_dim, int seq_len, float* out, hipStream_t s) {
-    ZG_REQUIRE(head_dim >= 1 && head_dim <= 2048 && n_heads >= 1 && n_heads < 65536 && batch >= 1 && batch < 65536 && seq_len >= 1, ZG_ERR_UNSUPPORTED,
+    if (batch == 0) return ZG_OK;  // k.len below one sequence: the reference's loop over the batch does nothing (ops.zig:259-261)
+    ZG_REQUIRE(head_dim >= 1 && head_dim <= 2048 && n_heads >= 1 && n_heads < 65536 && batch >= 1 && seq_len >= 1, ZG_ERR_UNSUPPORTED,
                "attention: head_dim %d / heads %d / batch %d", head_dim, n_heads, batch);
-    hipLaunchKernelGGL(attn_any_dim_kernel, dim3(n_heads, batch), dim3(256), 0, s, q, k, v, stride_b, stride_h, stride_t, n_heads, head_dim, seq_len, out);
-    ZG_HIP(hipGetLastError());
+    for (int b0 = 0; b0 < batch; b0 += 65535) {  // (the grid's y extent ends at 65535)
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(attn_any_dim_kernel, dim3(n_heads, nb), dim3(256), 0, s, q + (size_t)b0 * n_heads * head_dim, k + (size_t)b0 * stride_b,
+                           v + (size_t)b0 * stride_b, stride_b, stride_h, stride_t, n_heads, head_dim, seq_len, out + (size_t)b0 * n_heads * head_dim);
+        ZG_HIP(hipGetLastError());
+    }
     return ZG_OK;
 }
 

@@ -6,11 +6,20 @@
 //
 // RCCL is bound at run time (dlopen of librccl.so; a copy already in the process — PyTorch's — is preferred, so that one
 // process never runs two): a one-GPU box without RCCL still loads libzgpt2_hip.so, and zg_dist_* then fail with a message.
+// Nothing of RCCL is needed at build time either: the handful of types and constants its C API passes are declared here.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
 #include "zg_runtime.h"
+
+// the part of rccl.h this file uses (stable NCCL ABI: a 128-byte opaque id, an opaque communicator, result 0 = success,
+// ncclUint8 = 1)
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint8 = 1;
 
 namespace zg {
 namespace {
@@ -37,7 +46,10 @@ int load_rccl() {
     if (!lib)
         for (const char* n : names)
             if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
-    ZG_REQUIRE(lib != nullptr, ZG_ERR_UNSUPPORTED, "multi-GPU: librccl.so not found (%s)", dlerror());
+    if (!lib) {
+        const char* why = dlerror();  // (may be NULL)
+        ZG_REQUIRE(false, ZG_ERR_UNSUPPORTED, "multi-GPU: librccl.so not found (%s)", why ? why : "no loader message");
+    }
     Rccl r;
     r.lib = lib;
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
@@ -72,6 +84,10 @@ int dist_broadcast(void* buf, size_t bytes, int root, hipStream_t s) {
 using namespace zg;
 
 extern "C" {
+
+// Not a collective: can this process bind RCCL at all?  Ranks agree on the answer BEFORE any of them enters zg_dist_init,
+// which is a rendezvous (ncclCommInitRank) the others would otherwise wait in for a rank that has already given up.
+int zg_dist_available(void) { return load_rccl(); }
 
 int zg_dist_unique_id(void* id_out, size_t id_bytes) {
     ZG_REQUIRE(id_out && id_bytes == ZG_DIST_ID_BYTES, ZG_ERR_ARG, "dist_unique_id: the id is %d bytes", ZG_DIST_ID_BYTES);

@@ -608,6 +608,8 @@ __global__ __launch_bounds__(256, 1) void gemm_s4_kernel(const bf16_t* __restric
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
+            // the partial's loads must not be hoisted above the flag: agent-scope acquire (the poll itself is relaxed)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(qa.sk_ws, 0, (unsigned)(G >> 1) * 196608u, 0x00020000);
             const unsigned base = (unsigned)(sk_sh * 4 + wave) * 49152u + (unsigned)lane * 16u;
             static_for<12>([&](auto QT) {
@@ -1084,7 +1086,7 @@ int launch_gemm_s4_prefill(const bf16_t* A, const bf16_t* W, const float* bias, 
             const int cus_env = getenv("ZGPT2_GEMM_WGS") ? atoi(getenv("ZGPT2_GEMM_WGS")) : 0;
             const int G = cus_env > 0 ? cus_env : 256, tiles = ((M + 255) / 256) * ((N + 191) / 192);
             if (qkv->sk_ws != nullptr && qkv->sk_flags != nullptr && G % 16 == 0 && tiles > G && (tiles % G) * 2 == G && pl.kpp % 2 == 0 &&
-                pl.kpp >= 4 && (size_t)(G / 2) * 196608 <= qkv->sk_ws_bytes)
+                pl.kpp >= 4 && (size_t)(G / 2) * 196608 <= qkv->sk_ws_bytes && (size_t)(G / 2) * 4 <= qkv->sk_flags_words)
                 return launch_s4_kind<3, S4_QKV, false, false, true>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
             return launch_s4_kind<3, S4_QKV, false, false>(A, W, bias, C, M, N, pl, ldc, 1, *qkv, s);
         }

@@ -223,6 +223,7 @@ struct PrefillQkv {
     void* sk_ws = nullptr;
     size_t sk_ws_bytes = 0;
     unsigned* sk_flags = nullptr;
+    unsigned sk_flags_words = 0;  // words behind sk_flags (4 per shared tile: G / 2 tiles for G workgroups)
     unsigned sk_epoch = 0;
 };
 struct PrefillLn {

@@ -39,6 +39,20 @@ class GPT:
         self.h = h
         self._L = L
 
+    @classmethod
+    def from_raw_dir(cls, path, config: GPTConfig, **kw):
+        """load_gpt (src/main.zig:304-314) from a reference-format weight directory.  The matrices keep the reference's fp32
+        unless every one of them is bf16-representable (weights_io.flags_for_checkpoint: bf16 storage of an ordinary fp32
+        checkpoint is 6e-3 of the logit scale away from the fp32 result, outside the 1e-3 bound)."""
+        from . import weights_io
+
+        w = weights_io.load_raw_dir(path, config)
+        flags = weights_io.flags_for_checkpoint(w)
+        flags.update(kw)
+        m = cls(config, **flags)
+        m.load_weights(w)
+        return m
+
     def close(self):
         if getattr(self, "h", None):
             self._L.zg_gpt_destroy(self.h)

@@ -48,3 +48,18 @@ def save_raw_dir(path, cfg: GPTConfig, weights):
     os.makedirs(path, exist_ok=True)
     for name, shape, _, _ in tensor_specs(cfg):
         np.ascontiguousarray(weights[name], dtype="<f4").reshape(-1).tofile(os.path.join(path, file_name(name)))
+
+
+def bf16_representable(a):
+    """True when rounding `a` to bf16 changes nothing (its low 16 mantissa bits are zero)."""
+    b = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return not bool(np.any(b & np.uint32(0xFFFF)))
+
+
+def flags_for_checkpoint(weights):
+    """How a handle should store the matrices of THIS checkpoint: bf16 storage is lossless only for bf16-representable
+    weights (the synthetic ones); on an ordinary fp32 checkpoint it moves the logits by about 1e-2 of their scale
+    (tests/test_weight_storage_gpu.py), outside north_star's 1e-3 — such a checkpoint gets ZG_GPT_WEIGHTS_F32, the reference's
+    own precision (src/main.zig:210-269 keeps fp32).  Returns keyword arguments for gpt.GPT."""
+    mats = [v for k, v in weights.items() if np.ndim(v) == 2]
+    return {"weights_f32": not all(bf16_representable(m) for m in mats)}
