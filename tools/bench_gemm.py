@@ -42,9 +42,10 @@ def measure(lib, m, n=3072, k=768, gelu=True, out_bf16=True, iters=50, batches=5
 
 if __name__ == "__main__":
     lib = _lib.load(); _lib.check(lib.zg_init(0))
-    if len(sys.argv) > 1:  # e.g. `bench_gemm.py 8192` or `bench_gemm.py 8192 4096 4096` (M N K)
-        a = [int(v) for v in sys.argv[1:]]
-        print(json.dumps(measure(lib, a[0], *(a[1:3] if len(a) >= 3 else ()))))
+    if len(sys.argv) > 1:  # e.g. `bench_gemm.py 8192` or `bench_gemm.py 8192 4096 4096` (M N K), `nogelu` / `f32` anywhere
+        gelu, bf16 = "nogelu" not in sys.argv, "f32" not in sys.argv
+        a = [int(v) for v in sys.argv[1:] if v.isdigit()]
+        print(json.dumps(measure(lib, a[0], *(a[1:3] if len(a) >= 3 else ()), gelu=gelu, out_bf16=bf16)))
         sys.exit(0)
     for m in (1024, 8192, 16384):
         print(json.dumps(measure(lib, m)))

@@ -18,6 +18,9 @@ ap.add_argument("--ctx", type=int, default=0)
 ap.add_argument("--prio", default="cycle", help="cycle (0, +1, -1, ...), normal (all 0), or a comma list of priorities")
 ap.add_argument("--prefetch", action="store_true", help="leave the side-stream L2 prefetcher to the library's default rule")
 ap.add_argument("--kv-b24", action="store_true")
+ap.add_argument("--like-bench", default="", help="comma list of what bench.py has done to the process before its groups table: "
+                "stream (torch stream as the library stream), rccl (one-rank communicator made and destroyed), handle (a one-prompt handle with "
+                "its prefetcher alive, one generation run), gemm (the GEMM bench)")
 ap.add_argument("groups", type=int, nargs="+")
 a = ap.parse_args()
 
@@ -30,6 +33,20 @@ for name, shape, mean, _ in synth.tensor_specs(cfg):
     t = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32) * 0.02 + mean
     w[name] = t.to(torch.bfloat16).to(torch.float32).contiguous()
 prompts = [synth.rand_tokens(2000 + b, 1, cfg.vocab_size) for b in range(a.prompts)]
+like = set(x for x in a.like_bench.split(",") if x)
+keep = []
+if "stream" in like:
+    st = torch.cuda.Stream(); _lib.check(lib.zg_set_stream(st.cuda_stream)); keep.append(st)
+if "rccl" in like:
+    import ctypes as C
+    uid = (C.c_ubyte * 128)()
+    _lib.check(lib.zg_dist_unique_id(uid, 128)); _lib.check(lib.zg_dist_init(uid, 128, 0, 1)); _lib.check(lib.zg_dist_finalize())
+if "handle" in like:
+    h = zgpt.GPT(cfg, batch=1); h.load_weights(w); h.generate_enqueue(prompts[:1], ctx); torch.cuda.synchronize(); keep.append(h)
+if "gemm" in like:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench_gemm
+    bench_gemm.measure(lib, 8192)
 ref_ids = None
 for G in a.groups:
     if a.prio == "cycle":
@@ -62,7 +79,7 @@ for G in a.groups:
     ids = m.generate_fetch(ctx)
     if ref_ids is None:
         ref_ids = ids
-    row = {"model": a.model, "prompts": a.prompts, "groups": G, "per_group": a.prompts // G, "priorities": a.prio, "prefetch": a.prefetch,
+    row = {"model": a.model, "prompts": a.prompts, "groups": G, "per_group": a.prompts // G, "priorities": a.prio, "prefetch": a.prefetch, "like_bench": a.like_bench,
            "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "tokens_per_s": round(a.prompts * (ctx - 1) * a.gens / wall, 1),
            "ms_per_generation": round(1e3 * wall / a.gens, 2), "us_per_step": round(1e6 * wall / a.gens / ctx, 2),
            "host_enqueue_ms_per_generation": round(1e3 * t_enq / a.gens, 2), "feeder_threads": os.environ.get("ZGPT2_MANY_THREADS", "1"),
