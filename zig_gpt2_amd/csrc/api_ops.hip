@@ -167,32 +167,68 @@ int Call::also_out(void* host, const void* dev_part, size_t bytes) {
     return ZG_OK;
 }
 
+void Call::reserve(unsigned** flag, unsigned* seq) {
+    Ctx& c = ctx();
+    *flag = nullptr;
+    *seq = 0;
+    if (c.done_flag == nullptr || c.calls_since_sync + 1 >= 256) return;
+    for (int i = 0; i < n_outs_; ++i)
+        if (outs_[i].dev != nullptr) return;  // a transfer must follow the kernel: its completion is not the call's
+    reserved_seq_ = ++c.done_seq;
+    reserved_ = true;
+    *flag = c.done_flag;
+    *seq = reserved_seq_;
+}
+
 int Call::finish() {
-    for (int i = 0; i < n_outs_; ++i) {
+    Ctx& c = ctx();
+    const bool poll = c.done_flag != nullptr && c.calls_since_sync + 1 < 256;
+    // Outputs that live in device memory.  A few small ones (the common case: _qkv and _q of an attention call) leave for the pinned
+    // arena in the SAME launch that announces the call's completion; anything else by DMA — outputs that lie back to back in both
+    // arenas (consecutive out() calls of 256-byte multiples) in one transfer.
+    CopySegs segs{};
+    size_t seg_bytes = 0;
+    bool fused = poll && !(reserved_ && announced_);
+    for (int i = 0; i < n_outs_ && fused; ++i) {
         if (outs_[i].dev == nullptr) continue;
-        // outputs that lie back to back in both arenas (consecutive out() calls of 256-byte multiples) leave in ONE transfer
-        size_t bytes = outs_[i].bytes;
-        int j = i;
-        while (outs_[i].pin != nullptr && j + 1 < n_outs_ && outs_[j + 1].dev != nullptr && outs_[j + 1].pin != nullptr &&
-               static_cast<char*>(outs_[i].dev) + bytes == static_cast<char*>(outs_[j + 1].dev) && outs_[i].pin + bytes == outs_[j + 1].pin) {
-            bytes += outs_[j + 1].bytes;
-            ++j;
+        if (outs_[i].pin == nullptr || segs.n == 4 || (outs_[i].bytes & 3) || outs_[i].bytes > (64u << 10)) fused = false;
+        else {
+            segs.src[segs.n] = outs_[i].dev;
+            segs.dst[segs.n] = outs_[i].pin;
+            segs.bytes[segs.n++] = (unsigned)outs_[i].bytes;
+            seg_bytes += outs_[i].bytes;
         }
-        ZG_HIP(hipMemcpyAsync(outs_[i].pin ? (void*)outs_[i].pin : outs_[i].host, outs_[i].dev, bytes, hipMemcpyDeviceToHost, s_));
-        i = j;
     }
+    fused = fused && segs.n > 0 && seg_bytes <= (64u << 10);
+    if (!fused)
+        for (int i = 0; i < n_outs_; ++i) {
+            if (outs_[i].dev == nullptr) continue;
+            size_t bytes = outs_[i].bytes;
+            int j = i;
+            while (outs_[i].pin != nullptr && j + 1 < n_outs_ && outs_[j + 1].dev != nullptr && outs_[j + 1].pin != nullptr &&
+                   static_cast<char*>(outs_[i].dev) + bytes == static_cast<char*>(outs_[j + 1].dev) && outs_[i].pin + bytes == outs_[j + 1].pin) {
+                bytes += outs_[j + 1].bytes;
+                ++j;
+            }
+            ZG_HIP(hipMemcpyAsync(outs_[i].pin ? (void*)outs_[i].pin : outs_[i].host, outs_[i].dev, bytes, hipMemcpyDeviceToHost, s_));
+            i = j;
+        }
     // Op-tier calls are synchronous on return: the reference's host code reads the buffers next.  The host polls a pinned
     // completion word stored in stream order behind the call's work (cheaper than the runtime's wake-up); every 256th call —
     // and any call whose word does not arrive — drains the stream the ordinary way, which also surfaces asynchronous errors.
-    Ctx& c = ctx();
     bool drained = false;
     if (c.done_flag != nullptr && ++c.calls_since_sync < 256) {
-        const unsigned seq = ++c.done_seq;
-        if (launch_done_flag(c.done_flag, seq, s_) == ZG_OK)
+        // (a reserved sequence number nobody announced is simply skipped: the next one is larger)
+        const bool own = reserved_ && announced_;
+        const unsigned seq = own ? reserved_seq_ : ++c.done_seq;
+        const int st = own ? ZG_OK : fused ? launch_copy_out_done(segs, c.done_flag, seq, s_) : launch_done_flag(c.done_flag, seq, s_);
+        if (st == ZG_OK)
             for (long spins = 0; spins < (1L << 24) && !drained; ++spins) {
                 drained = __atomic_load_n(c.done_flag, __ATOMIC_ACQUIRE) == seq;
                 if (!drained) __builtin_ia32_pause();
             }
+        else if (fused)
+            return st;  // (the outputs have not left: the call failed)
     }
     if (!drained) {
         ZG_HIP(hipStreamSynchronize(s_));
@@ -203,6 +239,7 @@ int Call::finish() {
     c.stage_off = mark_;
     c.pin_off = pin_mark_;
     n_outs_ = 0;
+    reserved_ = announced_ = false;
     return ZG_OK;
 }
 
@@ -604,7 +641,12 @@ int zg_embedding_forward(size_t emb_dim, const float* weight, size_t weight_len,
     ZG_TRY(call.param(weight, weight_len, &w));
     ZG_TRY(call.in_once(idxs, idxs_len, &ix));
     ZG_TRY(call.out_once(embeddings, idxs_len * emb_dim, &out));
-    ZG_TRY(launch_embedding(w, emb_dim, ix, idxs_len, weight_len / emb_dim, out, ctx().d_flag, call.stream()));
+    unsigned* df;
+    unsigned ds;
+    bool own = false;
+    call.reserve(&df, &ds);
+    ZG_TRY(launch_embedding(w, emb_dim, ix, idxs_len, weight_len / emb_dim, out, ctx().d_flag, call.stream(), df, ds, &own));
+    call.announced(own);
     ZG_TRY(call.finish());
     guard.done = true;
     if (*static_cast<volatile int*>(ctx().d_flag)) {  // raised by the kernel (pinned host word), read behind the call's drain
@@ -630,7 +672,12 @@ int zg_layernorm_forward(size_t n_features, const float* weight, const float* bi
     ZG_TRY(call.param(weight, n_features, &g));
     ZG_TRY(call.param(bias, n_features, &b));
     ZG_TRY(call.inout_once(inputs, inputs_len, &x));
-    ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream()));
+    unsigned* df;
+    unsigned ds;
+    bool own = false;
+    call.reserve(&df, &ds);
+    ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream(), df, ds, &own));
+    call.announced(own);
     ZG_TRY(call.finish());
     guard.done = true;
     return ZG_OK;
@@ -644,7 +691,12 @@ int zg_gelu(float* inputs, size_t inputs_len) {
     CallGuard guard(call);
     float* x;
     ZG_TRY(call.inout_once(inputs, inputs_len, &x));
-    ZG_TRY(launch_gelu(x, inputs_len, call.stream()));
+    unsigned* df;
+    unsigned ds;
+    bool own = false;
+    call.reserve(&df, &ds);
+    ZG_TRY(launch_gelu(x, inputs_len, call.stream(), df, ds, &own));
+    call.announced(own);
     ZG_TRY(call.finish());
     guard.done = true;
     return ZG_OK;
@@ -657,7 +709,12 @@ int zg_softmax(float* inputs, size_t inputs_len) {
     CallGuard guard(call);
     float* x;
     ZG_TRY(call.inout_once(inputs, inputs_len, &x));
-    ZG_TRY(launch_softmax(x, inputs_len, call.stream()));
+    unsigned* df;
+    unsigned ds;
+    bool own = false;
+    call.reserve(&df, &ds);
+    ZG_TRY(launch_softmax(x, inputs_len, call.stream(), df, ds, &own));
+    call.announced(own);
     ZG_TRY(call.finish());
     guard.done = true;
     return ZG_OK;
@@ -821,8 +878,7 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     // c_attn (ops.zig:143)
     ZG_TRY(linear_device(E, 3 * E, caw, cab, x, 1, qkv, s));
     // cache append (ops.zig:151-152, :156-157): into the device cache, and — for mirrored host caches — row T-1 back to the caller
-    ZG_TRY(launch_copy_f32(qkv + E, kc + (seq_len - 1) * E, E, s));
-    ZG_TRY(launch_copy_f32(qkv + 2 * E, vc + (seq_len - 1) * E, E, s));
+    ZG_TRY(launch_copy2_f32(qkv + E, kc + (seq_len - 1) * E, qkv + 2 * E, vc + (seq_len - 1) * E, E, s));
     if (mir[0]) ZG_TRY(call.also_out(k_cache + (seq_len - 1) * E, qkv + E, E * sizeof(float)));
     if (mir[1]) ZG_TRY(call.also_out(v_cache + (seq_len - 1) * E, qkv + 2 * E, E * sizeof(float)));
     // attention straight over the [T, H, hd] cache (replaces transposes + sdpa, ops.zig:153-171);

@@ -149,12 +149,21 @@ int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, i
 
 // ------------------------------------------------------------------------------------ elementwise
 int launch_epoch_bump(unsigned* epoch, hipStream_t s);  // measurement chains: advance the tag epoch (api_gpt.hip zg_gpt_time_kernel)
-int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s);
-int launch_gelu(float* x, size_t n, hipStream_t s);
-int launch_softmax(float* x, size_t n, hipStream_t s);
+int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s, unsigned* done_flag = nullptr,
+                     unsigned done_seq = 0, bool* announced = nullptr);
+int launch_gelu(float* x, size_t n, hipStream_t s, unsigned* done_flag = nullptr, unsigned done_seq = 0, bool* announced = nullptr);
+int launch_softmax(float* x, size_t n, hipStream_t s, unsigned* done_flag = nullptr, unsigned done_seq = 0, bool* announced = nullptr);
 int launch_done_flag(unsigned* flag, unsigned seq, hipStream_t s);
+struct CopySegs {  // up to four device -> pinned-host segments (16-byte aligned, multiples of 4 bytes)
+    const void* src[4];
+    void* dst[4];
+    unsigned bytes[4];
+    int n;
+};
+int launch_copy_out_done(const CopySegs& segs, unsigned* flag, unsigned seq, hipStream_t s);
+int launch_copy2_f32(const float* a, float* da, const float* b, float* db, size_t n, hipStream_t s);
 int launch_embedding(const float* w, size_t emb_dim, const size_t* idx, size_t n_idx, size_t n_rows,
-                     float* out, int* d_oob_flag, hipStream_t s);
+                     float* out, int* d_oob_flag, hipStream_t s, unsigned* done_flag = nullptr, unsigned done_seq = 0, bool* announced = nullptr);
 int launch_split_qkv(const float* in, size_t rows, size_t n_embed, size_t split_idx, float* out, hipStream_t s);
 int launch_transpose(const float* in, size_t batch, size_t t, size_t n, size_t h, float* out, hipStream_t s);
 int launch_copy_f32(const float* in, float* out, size_t n, hipStream_t s);

@@ -101,6 +101,12 @@ class Call {
     }
     // A second host destination for a part of an output already staged with out() (the cache rows inside _qkv).
     int also_out(void* host, const void* dev_part, size_t bytes);
+    // A call whose LAST kernel is a single workgroup writing zero-copy outputs may let that kernel store the completion word
+    // itself: reserve() hands out the word and the sequence number finish() will poll for (flag == nullptr: not available —
+    // polling is off, the periodic real drain is due, or an output of this call still needs a DMA behind the kernel);
+    // announced(true) tells finish() that the kernel took it, so the one-thread launch is skipped.
+    void reserve(unsigned** flag, unsigned* seq);
+    void announced(bool yes) { announced_ = yes; }
     // Copies outputs back (if any were staged), synchronises the stream, releases the arenas.
     int finish();
     hipStream_t stream() const { return s_; }
@@ -118,6 +124,8 @@ class Call {
     };
     Out outs_[24];
     int n_outs_ = 0;
+    unsigned reserved_seq_ = 0;
+    bool reserved_ = false, announced_ = false;
     size_t mark_, pin_mark_;
     hipStream_t s_;
 };
