@@ -375,7 +375,9 @@ def other_config(lib, stream, model_name, ppg, gens, seed, kv_b24=False):
             "lm_head": {k: lm[k] for k in ("kernel_symbol", "avg_launch_us", "GBps", "frac_of_8TBps")},
             "prefill": {"prompt_tokens": ctx - 1, "prompts": ppg, "ms": round(pf_ms, 3), "prompt_tokens_per_s": round(ppg * (ctx - 1) / pf_ms * 1e3, 1),
                         **prefill_flops(cfg, ppg, ctx - 1, pf_ms)},
-            "checked": False,  # timed only: the same shapes are held to the oracle by pytest (tests/test_full_configs_gpu.py, test_prefill_gpu.py)
+            # timed only.  bench.py may use the oracle in its cpu_baseline leg and nowhere else; the same shapes are held to the oracle
+            # at full context by pytest (tests/test_full_configs_gpu.py, test_prefill_gpu.py)
+            "checked": False,
             "data": "synthetic (torch.randn on the GPU, bf16-representable)", "first_tokens": [int(t) for t in ids[0, :4]],
         }
     finally:
@@ -769,6 +771,9 @@ def main():
             "achieved": round(step_bytes_total * a.steps / dev_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(step_bytes_total * a.steps / dev_s / 1e9 / HBM_PEAK_GBS, 4),
             "us_per_token_device": round(1e6 * dev_s / (a.steps * ctx), 2),
+            # two clocks that do not share code: torch events around the whole generations (above) against the sum of the per-class
+            # chain timings of kernel_classes (the library's HIP events around hipGraph chains), priced per token with the embed launch
+            "sum_of_kernel_class_chains_us": round(sum(r["avg_launch_us_layers_walked"] * r["launches_per_token"] for r in table) + prof_lo.get("embed", 0.0), 2),
             "per_kernel_class_us_eager_T_low": {k: round(v, 2) for k, v in prof_lo.items()},
             "per_kernel_class_us_eager_T_high": {k: round(v, 2) for k, v in prof_hi.items()},
         },
