@@ -25,3 +25,18 @@ def test_round_trip_and_size_check(tmp_path):
         f.write(b"\0\0\0\0")
     with pytest.raises(ValueError):
         weights_io.load_raw_dir(tmp_path, cfg)
+
+
+def test_checkpoint_storage_policy():
+    """bf16 storage is lossless only for bf16-representable matrices; anything else keeps the reference's fp32
+    (tests/test_weight_storage_gpu.py measures why: 6e-3 of the logit scale at 124M)."""
+    cfg = synth.CONFIGS["tiny"]
+    assert weights_io.flags_for_checkpoint(synth.make_weights(cfg, seed=3, bf16=True)) == {"weights_f32": False}
+    w = synth.make_weights(cfg, seed=3, bf16=False)
+    assert weights_io.flags_for_checkpoint(w) == {"weights_f32": True}
+    # one unrounded matrix is enough; vectors (biases, LayerNorm) never decide — they stay fp32 in every handle
+    w2 = synth.make_weights(cfg, seed=3, bf16=True)
+    w2["h0.c_attn_b"] = w["h0.c_attn_b"]
+    assert weights_io.flags_for_checkpoint(w2) == {"weights_f32": False}
+    w2["h1.c_fc_w"] = w["h1.c_fc_w"]
+    assert weights_io.flags_for_checkpoint(w2) == {"weights_f32": True}
