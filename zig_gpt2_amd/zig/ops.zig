@@ -13,6 +13,13 @@
 //!     exe.addLibraryPath(.{ .path = "zig_gpt2_amd/lib" });
 //!     exe.linkSystemLibrary("zgpt2_hip");
 //! in place of `exe.linkFramework("Accelerate")` (build.zig:30, :71).
+//!
+//! What the library does behind these calls so that an unchanged main.zig is not slow (include/zgpt2.h, INTEGRATION.md §4):
+//! weights are mirrored on the device once (`zg_register_tensor` in `init`); the small activation slices of `State` travel through
+//! a pinned arena (kernels that touch a slice once work on it in place); the k/v caches a `Block` owns are mirrored on the device,
+//! keyed by their address, so `CausalSelfAttention.forward` uploads nothing while `seq_len` advances by one and returns only the
+//! appended row.  A caller that rewrites cache rows it has already handed over must call `zg_unregister_tensor(cache.ptr)` first
+//! (main.zig never does).  The C++ restatement of main.zig over the same ABI runs ~0.8 k tokens/s at GPT-2 124M.
 const std = @import("std");
 
 const c = struct {
