@@ -26,10 +26,15 @@ for seed in range(first, first + count):
     n_steps = int(rng.integers(2, min(cfg.context_size, max_steps) + 1))
     lens = [int(rng.integers(1, max(2, min(n_steps, 40)))) for _ in range(batch)]
     prompts = [synth.rand_tokens(5100 + 17 * seed + b, lens[b], cfg.vocab_size) for b in range(batch)]
-    what = f"seed {seed}: {name} batch {batch} steps {n_steps} lens {lens} {kw}"
+    # a third of the configurations run as co-running prompt GROUPS (one handle per group, own streams, shared weights) instead of
+    # one lock-step handle: same tokens expected (a separate generator, so that the configurations above keep their seeds)
+    rng_g = np.random.default_rng(91000 + seed)
+    divisors = [g for g in (2, 4, 8) if batch % g == 0]
+    groups = int(rng_g.choice(divisors)) if divisors and rng_g.integers(0, 3) == 0 else 1
+    what = f"seed {seed}: {name} batch {batch} groups {groups} steps {n_steps} lens {lens} {kw}"
     try:
         w = synth.make_weights(cfg, seed=200 + seed, bf16=not f32)
-        m = zgpt.GPT(cfg, batch=batch, **kw)
+        m = zgpt.GPTGroups(cfg, batch, groups, **kw) if groups > 1 else zgpt.GPT(cfg, batch=batch, **kw)
         m.load_weights(w)
         ids = m.generate(prompts, n_steps)
         m.close()
