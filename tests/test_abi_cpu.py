@@ -61,3 +61,13 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".zig")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in text and "from oracle" not in text and "zgpt2_oracle" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/zgpt2.h must compile as C99 with nothing but the standard headers (no HIP, no C++)."""
+    import subprocess
+
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "%s"\nint main(void) { zg_gpt_options o; zg_gpt_config c; o.share_weights_with = 0; o.own_stream = 1; '
+                   'o.stream_priority = 0; c.n_embed = 768; return (int)(sizeof(o) + sizeof(c) + ZG_N_BLOCK_SLOTS + ZG_DIST_ID_BYTES) == 0; }\n' % _lib.HEADER)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-c", str(src), "-o", str(tmp_path / "hdr.o")])
