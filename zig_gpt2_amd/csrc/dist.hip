@@ -8,6 +8,7 @@
 // process never runs two): a one-GPU box without RCCL still loads libzgpt2_hip.so, and zg_dist_* then fail with a message.
 // Nothing of RCCL is needed at build time either: the handful of types and constants its C API passes are declared here.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "zg_runtime.h"
@@ -41,8 +42,17 @@ int load_rccl() {
     if (g_rccl.lib) return ZG_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
+    // ZGPT2_RCCL_LIB (test hook): bind the six entry points from this library instead — tests/stub_rccl/ moves the bytes through
+    // files so that a world of several ranks can run on a one-GPU box, where RCCL refuses two ranks on one device
+    if (const char* forced = getenv("ZGPT2_RCCL_LIB")) {
+        lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) {
+            const char* why = dlerror();
+            ZG_REQUIRE(false, ZG_ERR_UNSUPPORTED, "multi-GPU: ZGPT2_RCCL_LIB=%s cannot be loaded (%s)", forced, why ? why : "no loader message");
+        }
+    }
     for (const char* n : names)  // a copy that is already mapped (torch/lib/librccl.so) first
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;
+        if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;
     if (!lib)
         for (const char* n : names)
             if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;

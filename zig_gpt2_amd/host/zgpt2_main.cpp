@@ -281,7 +281,10 @@ static bool read_all(int fd, void* buf, size_t n) {
 static int run_rank(int rank, int world, const GPTConfig& c, const std::string& wsrc, bool from_dir, uint64_t seed,
                     const std::vector<std::vector<size_t>>& prompts, size_t n_steps, int id_in_fd, const std::vector<int>& id_out_fds, int out_fd) {
     try {
-        ops::check(zg_init(rank));
+        // (ZGPT2_ALL_RANKS_ON_DEVICE=d: test hook — every rank on device d, with tests/stub_rccl as the transport, so that the
+        // rank plumbing of this program can run with N > 1 on a one-GPU box)
+        const char* one_dev = getenv("ZGPT2_ALL_RANKS_ON_DEVICE");
+        ops::check(zg_init(one_dev ? atoi(one_dev) : rank));
         unsigned char id[ZG_DIST_ID_BYTES];
         if (rank == 0) {
             ops::check(zg_dist_unique_id(id, sizeof id));
