@@ -445,7 +445,14 @@ def main():
     from zig_gpt2_amd import _lib, gpt, shard, synth
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
+    # Test hooks (tests/test_bench_gpu.py): ZGPT2_ALL_RANKS_ON_DEVICE=d puts every rank on device d, ZGPT2_RCCL_LIB names a stand-in
+    # for RCCL (tests/stub_rccl) — then torch's own collectives run over gloo on CPU tensors, since RCCL refuses two ranks on one
+    # GPU.  Everything else of the N > 1 path is the code a multi-GPU node runs.
+    one_dev = os.environ.get("ZGPT2_ALL_RANKS_ON_DEVICE")
+    dev_index = int(one_dev) if one_dev is not None else local_rank
+    backend = "gloo" if os.environ.get("ZGPT2_RCCL_LIB") else "nccl"
+    coll_dev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+    torch.cuda.set_device(dev_index)
     dist = None
     # ZGPT2_FORCE_DIST=1 runs the RCCL path (process group, weight broadcast, barriers, max-reduce) with a
     # single rank: the only way to exercise it on a one-GPU box
@@ -454,10 +461,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     lib = _lib.load()  # no fallback: raises if libzgpt2_hip.so is missing
-    _lib.check(lib.zg_init(local_rank))
+    _lib.check(lib.zg_init(dev_index))
     stream = torch.cuda.Stream()
     _lib.check(lib.zg_set_stream(stream.cuda_stream))
 
@@ -487,7 +497,7 @@ def main():
     def all_ranks_ok(ok):  # every rank takes the same branch: the native path only if it worked everywhere
         if not use_dist:
             return ok
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
@@ -549,7 +559,7 @@ def main():
         # the run must still measure the step: the same weight region through torch.distributed's broadcast (RCCL as well), and
         # the line says so
         ptr, nbytes = model.weight_arena()
-        arena = torch.as_tensor(_DevMem(ptr, nbytes), device=torch.device("cuda", local_rank))
+        arena = torch.as_tensor(_DevMem(ptr, nbytes), device=torch.device("cuda", dev_index))
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.perf_counter()
@@ -599,7 +609,7 @@ def main():
     dev_s = e0.elapsed_time(e1) / 1e3
     elapsed = wall_s
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ids = model.generate_fetch(ctx)
@@ -612,7 +622,7 @@ def main():
     scaling_extra = {}
     if dist is not None:
         _, wbytes_region = model.weight_arena()
-        scaling_extra = scaling_fields(dist, torch, torch.device("cuda", local_rank), world, value, ref_value,
+        scaling_extra = scaling_fields(dist, torch, coll_dev, world, value, ref_value,
                                        gen_tokens * a.steps / own_s, bcast_ms, wbytes_region)
     if rank != 0:
         if dist is not None:

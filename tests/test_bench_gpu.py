@@ -47,3 +47,28 @@ def test_bench_rccl_leg_with_one_rank():
     assert 0.7 < d["scaling_efficiency"] < 1.4, d["scaling_efficiency"]
     assert d["per_rank_tokens_per_s"]["min"] == d["per_rank_tokens_per_s"]["max"] > 0
     assert d["weight_broadcast_GBps"] is None or d["weight_broadcast_GBps"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_over_the_stub_transport():
+    """`python bench.py --gpus 2` end to end — self-launch through torch.distributed.run, the ranks agreeing that the collective
+    library binds, the id from rank 0, zg_dist_init on both, rank 1 RECEIVING the weights, the one-GPU reference taken by rank 0
+    alone, the timed region between barriers, the max over ranks, the scaling fields — with both ranks on device 0 and the
+    stand-in transport of tests/stub_rccl (RCCL refuses two ranks on one GPU; torch's own collectives then run over gloo).  Two
+    chains share one GPU here, so the efficiency is about a half, not one: the test checks the plumbing, not the speed."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub_src = os.path.join(root, "tests", "stub_rccl", "stub_rccl.cpp")
+    stub_so = os.path.join(root, "tests", "stub_rccl", "libstub_rccl.so")
+    if not os.path.exists(stub_so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", stub_so, stub_src])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZGPT2_RCCL_LIB=stub_so, ZGPT2_ALL_RANKS_ON_DEVICE="0")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--ctx", "64", "--prompts-per-gpu", "2"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_prompts"] == 4
+    assert d["weight_broadcast"].startswith("zg_gpt_broadcast_weights"), d["weight_broadcast"]  # the native path, not the torch fall-back
+    assert d["weight_broadcast_ms"] is not None and d["weight_broadcast_GBps"] > 0
+    assert d["scaling_reference"]["n_gpus"] == 1 and d["scaling_reference"]["value"] > 0
+    assert 0.2 < d["scaling_efficiency"] < 1.3, d["scaling_efficiency"]
+    assert 0 < d["per_rank_tokens_per_s"]["min"] <= d["per_rank_tokens_per_s"]["max"]
