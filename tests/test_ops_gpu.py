@@ -341,6 +341,45 @@ def test_attn_forward_cache_mirror_follows_the_callers_cache(zg):
         step(ref2, t, xs[t + 20], kc=v_cache, vc=k_cache)
 
 
+def test_device_twin_of_an_elementwise_result_is_only_used_for_unchanged_bytes(zg):
+    """The op tier keeps the result of an in-place LayerNorm / gelu on a HOST buffer in device memory as well, and the next Linear
+    that is handed the same buffer reads that twin instead of uploading the bytes again (in src/main.zig every Linear's input is
+    the previous op's output).  The twin must not survive a change of the caller's buffer: same pointer, one float edited (the
+    host loops of src/main.zig:136-145 do exactly that), a shorter slice, another buffer."""
+    e, n = 768, 320
+    w = synth.fill_normal(301, n * e, 0, 0.05).reshape(n, e)
+    lin = ops.Linear(e, n, w, None)
+    g, b = synth.fill_normal(302, e, 1, 0.1), synth.fill_normal(303, e, 0, 0.1)
+    ln = ops.LayerNorm(e, g, b)
+
+    def ref_linear(x):
+        return (x.reshape(-1, e).astype(np.float64) @ w.astype(np.float64).T).ravel()
+
+    x = synth.fill_normal(304, e, 0.2, 1.5)
+    ln.forward(x)                                   # x now holds the LayerNorm output; the library keeps a device twin
+    y = z(n)
+    lin.forward(x, y)                               # served from the twin
+    assert np.abs(y - ref_linear(x)).max() < 1e-4
+    x[5] += 3.0                                     # the caller edits ONE element on the host
+    lin.forward(x, y)
+    assert np.abs(y - ref_linear(x)).max() < 1e-4, "stale device twin used after the caller changed its buffer"
+    ln.forward(x)
+    lin2 = ops.Linear(e // 2, n, np.ascontiguousarray(w[:, : e // 2]), None)
+    lin2.forward(x[: e // 2], y)                    # a shorter slice of the same buffer: another length, no twin
+    assert np.abs(y - (x[: e // 2].astype(np.float64) @ w[:, : e // 2].astype(np.float64).T)).max() < 1e-4
+    other = x.copy()
+    lin.forward(other, y)                           # equal bytes at another address: uploaded as usual, same result
+    assert np.abs(y - ref_linear(x)).max() < 1e-4
+    h = synth.fill_normal(305, 4 * e, 0, 1.0)
+    w2 = synth.fill_normal(306, n * 4 * e, 0, 0.03).reshape(n, 4 * e)
+    ops.gelu(h)                                     # the gelu -> mlp c_proj pair of src/main.zig:79-81
+    ops.Linear(4 * e, n, w2, None).forward(h, y)
+    assert np.abs(y - (h.astype(np.float64) @ w2.astype(np.float64).T)).max() < 1e-4
+    h[100] = -h[100] + 0.5
+    ops.Linear(4 * e, n, w2, None).forward(h, y)
+    assert np.abs(y - (h.astype(np.float64) @ w2.astype(np.float64).T)).max() < 1e-4
+
+
 def test_error_behaviour(zg):
     x = z(10)
     assert zg.zg_layernorm_forward(768, x.ctypes.data, x.ctypes.data, 1e-5, x.ctypes.data, 10) == -2  # ZG_ERR_SHAPE

@@ -111,6 +111,13 @@ int Call::stage_in(const void* p, size_t bytes, bool is_param, bool once, const 
         *dev = p;
         return ZG_OK;
     }
+    {   // the previous op's result, still on the device?  (same buffer, same length, and the caller has not changed a byte of it)
+        Ctx& c = ctx();
+        if (!is_param && !once && p == c.shadow_ptr && bytes == c.shadow_bytes && memcmp(p, c.shadow_host, bytes) == 0) {
+            *dev = c.shadow_dev;
+            return ZG_OK;
+        }
+    }
     char* pin = pin_alloc(bytes);
     if (pin != nullptr) {
         memcpy(pin, p, bytes);
@@ -432,6 +439,12 @@ int zg_init_ex(int device, size_t staging_bytes) {
     c.kv_pool_cap = env_mb("ZGPT2_KV_MIRROR_MB", 1024) << 20;
     if (c.kv_pool_cap > 0) ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.kv_pool), c.kv_pool_cap));
     c.kv_pool_off = 0;
+    c.shadow_cap = (size_t)1 << 20;
+    ZG_HIP(hipMalloc(reinterpret_cast<void**>(&c.shadow_dev), c.shadow_cap));
+    c.shadow_host = static_cast<char*>(malloc(c.shadow_cap));
+    ZG_REQUIRE(c.shadow_host != nullptr, ZG_ERR_HIP, "zg_init: out of host memory");
+    c.shadow_ptr = nullptr;
+    c.shadow_bytes = 0;
     ZG_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.d_flag), 64, hipHostMallocDefault));
     *c.d_flag = 0;
     c.done_flag = reinterpret_cast<unsigned*>(c.d_flag) + 8;
@@ -467,6 +480,8 @@ int zg_shutdown(void) {
     (void)hipFree(c.stage);
     if (c.pin) (void)hipHostFree(c.pin);
     if (c.kv_pool) (void)hipFree(c.kv_pool);
+    if (c.shadow_dev) (void)hipFree(c.shadow_dev);
+    free(c.shadow_host);
     (void)hipHostFree(c.d_flag);
     (void)hipFree(c.d_zero);
     (void)hipFree(c.attn_part);
@@ -676,10 +691,19 @@ int zg_layernorm_forward(size_t n_features, const float* weight, const float* bi
     unsigned ds;
     bool own = false;
     call.reserve(&df, &ds);
-    ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream(), df, ds, &own));
+    Ctx& c = ctx();
+    const size_t bytes = inputs_len * sizeof(float);
+    const bool twin = static_cast<void*>(x) != static_cast<void*>(inputs) && bytes <= c.shadow_cap;  // a host buffer: keep a device twin of the result
+    c.shadow_ptr = nullptr;
+    ZG_TRY(launch_layernorm(x, (int)rows, (int)n_features, g, b, eps, call.stream(), df, ds, &own, twin ? c.shadow_dev : nullptr));
     call.announced(own);
     ZG_TRY(call.finish());
     guard.done = true;
+    if (twin) {
+        memcpy(c.shadow_host, inputs, bytes);
+        c.shadow_ptr = inputs;
+        c.shadow_bytes = bytes;
+    }
     return ZG_OK;
 }
 
@@ -695,10 +719,19 @@ int zg_gelu(float* inputs, size_t inputs_len) {
     unsigned ds;
     bool own = false;
     call.reserve(&df, &ds);
-    ZG_TRY(launch_gelu(x, inputs_len, call.stream(), df, ds, &own));
+    Ctx& c = ctx();
+    const size_t bytes = inputs_len * sizeof(float);
+    const bool twin = static_cast<void*>(x) != static_cast<void*>(inputs) && bytes <= c.shadow_cap;
+    c.shadow_ptr = nullptr;
+    ZG_TRY(launch_gelu(x, inputs_len, call.stream(), df, ds, &own, twin ? c.shadow_dev : nullptr));
     call.announced(own);
     ZG_TRY(call.finish());
     guard.done = true;
+    if (twin) {
+        memcpy(c.shadow_host, inputs, bytes);
+        c.shadow_ptr = inputs;
+        c.shadow_bytes = bytes;
+    }
     return ZG_OK;
 }
 

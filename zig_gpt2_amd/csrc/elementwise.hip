@@ -53,7 +53,9 @@ __device__ inline void announce_done(const DoneWord d) {
 // between the statistics and the normalisation: every element is read once and written once (the op tier hands small host
 // buffers over in place, across PCIe).
 __global__ __launch_bounds__(256) void layernorm_kernel(float* x, int rows, int n, const float* g,
-                                                        const float* b, float eps, DoneWord done) {
+                                                        const float* b, float eps, DoneWord done, float* shadow) {
+    // shadow (op tier, may be null): a device-memory twin of the result — x itself may be pinned host memory the NEXT op's
+    // kernels should not read across PCIe (api_ops.hip: the output of one op is the input of the next Linear in src/main.zig)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row < rows) {
@@ -78,7 +80,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* x, int rows, int 
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 const int i = lane + 64 * j;
-                if (i < n) r[i] = (v[j] - mean) / std_ * g[i] + b[i];
+                if (i < n) {
+                    const float y = (v[j] - mean) / std_ * g[i] + b[i];
+                    r[i] = y;
+                    if (shadow) shadow[(size_t)row * n + i] = y;
+                }
             }
         } else {
             for (int i = lane; i < n; i += 64) {
@@ -90,14 +96,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* x, int rows, int 
             s2 = wave_allsum(s2);
             const float mean = s1 / (float)n;
             const float std_ = sqrtf(s2 / (float)n - mean * mean + eps);
-            for (int i = lane; i < n; i += 64) r[i] = (r[i] - mean) / std_ * g[i] + b[i];
+            for (int i = lane; i < n; i += 64) {
+                const float y = (r[i] - mean) / std_ * g[i] + b[i];
+                r[i] = y;
+                if (shadow) shadow[(size_t)row * n + i] = y;
+            }
         }
     }
     announce_done(done);  // (asked for only when the grid is one workgroup)
 }
 
 // gelu (src/ops.zig:221-228), in place.
-__global__ __launch_bounds__(1024) void gelu_kernel(float* x, size_t n, DoneWord done) {
+__global__ __launch_bounds__(1024) void gelu_kernel(float* x, size_t n, DoneWord done, float* shadow) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n4 = n / 4;
     f32x4* x4 = reinterpret_cast<f32x4*>(x);
@@ -105,9 +115,13 @@ __global__ __launch_bounds__(1024) void gelu_kernel(float* x, size_t n, DoneWord
         f32x4 v = x4[i];
         v.x = gelu_ref(v.x); v.y = gelu_ref(v.y); v.z = gelu_ref(v.z); v.w = gelu_ref(v.w);
         x4[i] = v;
+        if (shadow) reinterpret_cast<f32x4*>(shadow)[i] = v;
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        x[i] = gelu_ref(x[i]);
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float y = gelu_ref(x[i]);
+        x[i] = y;
+        if (shadow) shadow[i] = y;
+    }
     announce_done(done);  // (asked for only when the grid is one workgroup)
 }
 
@@ -422,21 +436,21 @@ inline int grid_for(size_t n, int block = 256, int cap = 2048) {
 // done_flag != nullptr: the caller would like the kernel to announce its own completion; *announced tells whether this launch
 // does (a one-workgroup grid), otherwise the caller's one-thread launch follows as usual.
 int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s, unsigned* done_flag, unsigned done_seq,
-                     bool* announced) {
+                     bool* announced, float* shadow) {
     if (announced) *announced = false;
     if (rows == 0) return ZG_OK;
     const bool own = done_flag != nullptr && rows <= 4;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, n, g, b, eps, DoneWord{own ? done_flag : nullptr, done_seq});
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, n, g, b, eps, DoneWord{own ? done_flag : nullptr, done_seq}, shadow);
     ZG_HIP(hipGetLastError());
     if (announced) *announced = own;
     return ZG_OK;
 }
 
-int launch_gelu(float* x, size_t n, hipStream_t s, unsigned* done_flag, unsigned done_seq, bool* announced) {
+int launch_gelu(float* x, size_t n, hipStream_t s, unsigned* done_flag, unsigned done_seq, bool* announced, float* shadow) {
     if (announced) *announced = false;
     if (n == 0) return ZG_OK;
     const bool own = done_flag != nullptr && n <= 4096;  // one workgroup of 1024 lanes, one vector of four each: a single pass
-    hipLaunchKernelGGL(gelu_kernel, dim3(own ? 1 : grid_for(n / 4 + 1)), dim3(own ? 1024 : 256), 0, s, x, n, DoneWord{own ? done_flag : nullptr, done_seq});
+    hipLaunchKernelGGL(gelu_kernel, dim3(own ? 1 : grid_for(n / 4 + 1)), dim3(own ? 1024 : 256), 0, s, x, n, DoneWord{own ? done_flag : nullptr, done_seq}, shadow);
     ZG_HIP(hipGetLastError());
     if (announced) *announced = own;
     return ZG_OK;

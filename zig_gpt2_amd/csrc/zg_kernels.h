@@ -150,8 +150,8 @@ int launch_attn_merge(const float* part, int batch, int n_heads, int head_dim, i
 // ------------------------------------------------------------------------------------ elementwise
 int launch_epoch_bump(unsigned* epoch, hipStream_t s);  // measurement chains: advance the tag epoch (api_gpt.hip zg_gpt_time_kernel)
 int launch_layernorm(float* x, int rows, int n, const float* g, const float* b, float eps, hipStream_t s, unsigned* done_flag = nullptr,
-                     unsigned done_seq = 0, bool* announced = nullptr);
-int launch_gelu(float* x, size_t n, hipStream_t s, unsigned* done_flag = nullptr, unsigned done_seq = 0, bool* announced = nullptr);
+                     unsigned done_seq = 0, bool* announced = nullptr, float* shadow = nullptr);
+int launch_gelu(float* x, size_t n, hipStream_t s, unsigned* done_flag = nullptr, unsigned done_seq = 0, bool* announced = nullptr, float* shadow = nullptr);
 int launch_softmax(float* x, size_t n, hipStream_t s, unsigned* done_flag = nullptr, unsigned done_seq = 0, bool* announced = nullptr);
 int launch_done_flag(unsigned* flag, unsigned seq, hipStream_t s);
 struct CopySegs {  // up to four device -> pinned-host segments (16-byte aligned, multiples of 4 bytes)

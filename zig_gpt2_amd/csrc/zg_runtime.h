@@ -38,6 +38,14 @@ struct Ctx {
     size_t kv_pool_cap = 0;
     size_t kv_pool_off = 0;
     std::unordered_map<const void*, KvMirror> kv_mirrors;
+    // the result of the last in-place elementwise op on a HOST buffer, kept twice: in device memory (what the next Linear reads
+    // instead of uploading the same bytes again — in src/main.zig every Linear's input is the previous op's output) and in host
+    // memory (what the caller's buffer is compared with before the device twin is trusted)
+    float* shadow_dev = nullptr;
+    char* shadow_host = nullptr;
+    size_t shadow_cap = 0;
+    const void* shadow_ptr = nullptr;
+    size_t shadow_bytes = 0;
     unsigned* done_flag = nullptr;  // pinned completion word of op-tier calls (d_flag + 8), its sequence number, calls since a real drain
     unsigned done_seq = 0;
     unsigned calls_since_sync = 0;
