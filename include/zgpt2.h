@@ -226,7 +226,8 @@ int zg_gpt_destroy(zg_gpt* g);
  * side by side: own_stream gives a handle a private stream (stream_priority: 0 normal, > 0 high, < 0 low — streams of
  * different priorities never share a hardware queue), share_weights_with lets it read the weight region of another handle of
  * the same config and weight flags instead of holding a copy (that handle loads / broadcasts the weights and must be destroyed
- * last).  zg_gpt_create(...) == zg_gpt_create_ex(..., NULL). */
+ * last).  A handle with a private stream runs without the side-stream L2 prefetcher unless ZGPT2_PREFETCH=1 forces it (the
+ * prefetcher's placement assumes one chain on the chip).  zg_gpt_create(...) == zg_gpt_create_ex(..., NULL). */
 typedef struct {
     zg_gpt* share_weights_with; /* NULL: own weight region */
     int own_stream;             /* 0: the library stream (zg_set_stream applies); 1: a private stream made here */

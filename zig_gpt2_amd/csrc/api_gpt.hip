@@ -648,7 +648,9 @@ int setup_prefetcher(zg_gpt* g) {
     g->pf_ev_main = g->pf_ev_side = nullptr;
     // Default: only where it was measured to pay — one sequence and Linears of a few MB (GPT-2 124M: 241 -> 224 us per
     // token; GPT-2 XL's 20 MB matrices cannot be fetched a launch ahead, 8 prompts gain < 1 %).  ZGPT2_PREFETCH=1 / 0 forces.
-    const bool small = g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
+    // (not beside co-running handles: a handle with a private stream is one of several chains on the chip — §3.3 of DESIGN.md — and
+    // the prefetcher's per-XCD placement follows ONE queue's block order; each would also park 96 polling workgroups)
+    const bool small = g->stream == nullptr && g->batch == 1 && 4 * g->cfg.n_embed * g->cfg.n_embed * g->wbytes <= ((size_t)6 << 20);
     const int want = env_int("ZGPT2_PREFETCH", small ? 1 : 0);
     if ((g->flags & ZG_GPT_NO_PREFETCH) || !want || gs(g) == nullptr) return ZG_OK;
     if (g->pf_njobs > 255) return ZG_OK;  // the progress word counts launches in 8 bits (n_layer >= 51): no prefetcher, not an error
