@@ -54,7 +54,7 @@ def test_bench_two_ranks_on_one_gpu_over_the_stub_transport():
     library binds, the id from rank 0, zg_dist_init on both, rank 1 RECEIVING the weights, the one-GPU reference taken by rank 0
     alone, the timed region between barriers, the max over ranks, the scaling fields — with both ranks on device 0 and the
     stand-in transport of tests/stub_rccl (RCCL refuses two ranks on one GPU; torch's own collectives then run over gloo).  Two
-    chains share one GPU here, so the efficiency is about a half, not one: the test checks the plumbing, not the speed."""
+    chains share one GPU here, so the efficiency says nothing: the test checks the plumbing, not the speed."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     stub_src = os.path.join(root, "tests", "stub_rccl", "stub_rccl.cpp")
     stub_so = os.path.join(root, "tests", "stub_rccl", "libstub_rccl.so")
@@ -70,5 +70,7 @@ def test_bench_two_ranks_on_one_gpu_over_the_stub_transport():
     assert d["weight_broadcast"].startswith("zg_gpt_broadcast_weights"), d["weight_broadcast"]  # the native path, not the torch fall-back
     assert d["weight_broadcast_ms"] is not None and d["weight_broadcast_GBps"] > 0
     assert d["scaling_reference"]["n_gpus"] == 1 and d["scaling_reference"]["value"] > 0
-    assert 0.2 < d["scaling_efficiency"] < 1.3, d["scaling_efficiency"]
+    # (two chains of two processes share ONE GPU: anything from 0.1 — both processes' queues time-sliced, DESIGN §3.3 — to about
+    # a half has been seen; the figure only has to be consistent with the line's own value and reference)
+    assert d["scaling_efficiency"] > 0 and abs(d["scaling_efficiency"] - d["value"] / (2 * d["scaling_reference"]["value"])) < 2e-3
     assert 0 < d["per_rank_tokens_per_s"]["min"] <= d["per_rank_tokens_per_s"]["max"]
