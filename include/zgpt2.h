@@ -102,7 +102,9 @@ int zg_layernorm_forward(size_t n_features, const float* weight, const float* bi
  * buffer; any other call (first sight, position 1 again, a jump, a repeated position) uploads rows
  * 0..seq_len-2 from the caller's buffer first.  A caller that EDITS rows it already handed over and
  * then continues with the next position must drop the mirror first (zg_unregister_tensor(cache)).
- * When the pool has no room for a cache, that cache is staged whole on every call, as before. */
+ * The pool is a bump allocator: when the caches of a call do not fit what is left of it, every mirror is dropped and the pool
+ * starts over (live caches upload once more at their next call); a cache larger than the whole pool is staged whole on every
+ * call, as before. */
 int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight,
                     const float* c_attn_bias, const float* c_proj_weight, const float* c_proj_bias,
                     size_t seq_len, const float* inputs, size_t inputs_len, float* k_cache,

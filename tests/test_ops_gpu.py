@@ -5,6 +5,8 @@ vectors (tests/golden/ops.npz, produced by the reference's generate_test_data.py
 tolerance (src/tests.zig:4-20).  The second block compares against the CPU oracle on seeded inputs
 over shapes / edge cases the reference's tests do not reach.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -339,6 +341,44 @@ def test_attn_forward_cache_mirror_follows_the_callers_cache(zg):
     ref2 = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, T)
     for t in range(1, 5):
         step(ref2, t, xs[t + 20], kc=v_cache, vc=k_cache)
+
+
+def test_attn_forward_cache_mirror_pool_starts_over_when_full():
+    """The mirrors of caller-owned caches live in a pool allocated at zg_init (ZGPT2_KV_MIRROR_MB).  A process that keeps making
+    new caches (every test of this file does) must not end on the slow whole-cache staging for good: when the pool cannot take
+    the caches of a call, all mirrors are dropped and it starts over.  Own process: a 2 MiB pool, caches of 0.5 MiB per slot."""
+    import subprocess
+    import sys
+
+    code = """
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import oracle
+from zig_gpt2_amd import _lib, ops, synth
+zg = _lib.load(); _lib.check(zg.zg_init(0))
+e, hds, T = 128, 2, 6
+caw = synth.fill_normal(70, 3 * e * e, 0, 0.08).reshape(3 * e, e); cab = synth.fill_normal(71, 3 * e, 0, 0.05)
+cpw = synth.fill_normal(72, e * e, 0, 0.08).reshape(e, e); cpb = synth.fill_normal(73, e, 0, 0.05)
+attn = ops.CausalSelfAttention(hds, e, ops.Linear(e, 3 * e, caw, cab), ops.Linear(e, e, cpw, cpb))
+z = lambda n: np.zeros(n, np.float32)
+keep = []
+for rnd in range(7):  # 14 caches x 0.5 MiB slots through a 2 MiB pool: it must start over several times
+    ref = oracle.CausalSelfAttention(hds, e, caw, cab, cpw, cpb, T)
+    kc, vc = z(T * e), z(T * e); keep += [kc, vc]
+    xs = synth.fill_normal(700 + rnd, T * e, 0, 1.0).reshape(T, e)
+    for s in range(T):
+        out = z(e)
+        attn.forward(s + 1, xs[s], kc[: (s + 1) * e], vc[: (s + 1) * e], out, z(3 * e), z(e), z(T * e), z(T * e), z(T))
+        exp = ref.forward(s + 1, xs[s])
+        assert np.abs(out - exp).max() < 1e-4 * max(1.0, np.abs(exp).max()), (rnd, s)
+    assert np.allclose(kc, ref.k_cache, atol=1e-6) and np.allclose(vc, ref.v_cache, atol=1e-6)
+# an older cache continues after its mirror was dropped: rows re-uploaded from the caller's buffer
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, ZGPT2_KV_MIRROR_MB="2"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_device_twin_of_an_elementwise_result_is_only_used_for_unchanged_bytes(zg):

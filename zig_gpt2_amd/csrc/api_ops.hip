@@ -868,6 +868,20 @@ int zg_attn_forward(size_t n_heads, size_t n_embed, const float* c_attn_weight, 
     KvMirror* mir[2] = {nullptr, nullptr};
     float* host_cache[2] = {k_cache, v_cache};
     float** dev_cache[2] = {&kc, &vc};
+    {   // The pool is a bump allocator and mirrors of caches the caller has long freed stay in it.  When this call's caches would
+        // not fit what is left, every mirror is dropped and the pool starts over (the live caches upload once more at their next
+        // call) — before any pointer into the map is taken.
+        size_t need_bytes = 0;
+        for (int i = 0; i < 2; ++i) {
+            if (is_device_ptr(host_cache[i])) continue;
+            auto it = c.kv_mirrors.find(host_cache[i]);
+            if (it == c.kv_mirrors.end() || it->second.cap_floats < seq_len * E) need_bytes += std::max(seq_len * E * 2, (size_t)1024 * E) * sizeof(float) + 256;
+        }
+        if (need_bytes > 0 && c.kv_pool_off > 0 && c.kv_pool_off + need_bytes > c.kv_pool_cap && need_bytes <= c.kv_pool_cap) {
+            c.kv_mirrors.clear();
+            c.kv_pool_off = 0;
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         if (is_device_ptr(host_cache[i])) {
             *dev_cache[i] = host_cache[i];
