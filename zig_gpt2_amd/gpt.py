@@ -195,7 +195,15 @@ class GPTGroups:
         self.config, self.n_prompts, self.groups = config, n_prompts, groups
         self._L = _lib.load()
         per = n_prompts // groups
-        pr = priorities if priorities is not None else [self.PRIORITIES[i % len(self.PRIORITIES)] for i in range(groups)]
+        # default: priorities dealt in turn up to four groups (three distinct hardware queues: 452 against 667 us per step round at
+        # 4 x 2), all alike beyond that (eight streams over three priority levels serialise completely: 2.1 ms against 0.94 at 8 x 1;
+        # profiles/round6_corun_ab_final.jsonl)
+        if priorities is not None:
+            pr = priorities
+        elif groups <= 4:
+            pr = [self.PRIORITIES[i % len(self.PRIORITIES)] for i in range(groups)]
+        else:
+            pr = [0] * groups
         self.members = []
         for i in range(groups):
             self.members.append(GPT(config, batch=per, share_weights_with=self.members[0] if i else None,
