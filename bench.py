@@ -662,7 +662,7 @@ def main():
 
             gemm = bench_gemm.measure(lib, 8192)  # BASELINE's point; the other heights beside it (same warm-up: the clocks need it)
             keep = ("M", "N", "K", "gelu", "out", "us", "us_min", "tflops", "mfma_frac_of_2.5PF")
-            gemm["other_M"] = [{k: v for k, v in bench_gemm.measure(lib, m).items() if k in keep} for m in (1024, 16384)]
+            gemm["other_M"] = [{k: v for k, v in bench_gemm.measure(lib, m).items() if k in keep} for m in (64, 1024, 16384)]  # M in {64, 1024, 8192}
             # the account beside the headline (same kernel, same launch path): the epilogue's share (bias only, no GELU), and the
             # MLP's OTHER 768 x 3072 Linear — mlp c_proj, N = 768, K = 3072 (src/main.zig:81) — whose tiles see 4 x the K per
             # epilogue: whole K at M = 16384 (256 tiles of 256 x 192 = one per CU); at M = 8192 its 128 tiles fill half the chip
