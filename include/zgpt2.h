@@ -315,8 +315,10 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
                             const size_t* prompt_lens, size_t n_steps);
 int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t out_len);
 /* The same for the prompts of several handles at once (handles on distinct streams: zg_gpt_create_ex): prompts is
- * [sum of the handles' batches, prompt_stride], rows in handle order, prompt_lens alike; every handle generates its own rows,
- * the handles' graph launches are enqueued turn by turn so that no hardware queue starves while another one is being filled.
+ * [sum of the handles' batches, prompt_stride], rows in handle order, prompt_lens alike; every handle generates its own rows.
+ * A graph launch returns only when its hardware queue has room, so the handles are fed by one short-lived feeder thread each
+ * (inside this call; ZGPT2_MANY_THREADS=0: one thread, one graph launch per handle in turn) — no queue starves while another
+ * one is being filled.
  * zg_gpt_generate_fetch_many drains every handle and returns out_tokens [sum of batches, n_steps] in the same row order.
  * Token for token the result equals one handle per prompt (sequences never interact). */
 int zg_gpt_generate_enqueue_many(zg_gpt* const* handles, size_t n_handles, const size_t* prompts, size_t prompt_stride,
