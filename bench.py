@@ -709,6 +709,30 @@ def main():
                                         "linear_tflops_useful": round(lin_flops / p2_ms / 1e9, 1)}
         except Exception as e:
             prefill = {"error": str(e)}
+    # generate as the reference runs it (src/main.zig:322-342: every token drawn by GPT.sample, temp 0.8 in main): the device loop
+    # with the sampler as a node of the captured step, and the per-token entry point zg_gpt_sample it replaces
+    sampled = None
+    if world == 1:
+        try:
+            model.generate_sample(prompts, ctx, 0.8, seed=a.seed)  # (captures the sampled graphs)
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            ids_s = model.generate_sample(prompts, ctx, 0.8, seed=a.seed)
+            s_wall = time.perf_counter() - t_s
+            n_pt = min(ctx, 128)
+            toks = [int(p[0]) for p in prompts]
+            model.sample(1, toks, 0.8, seed=a.seed)
+            t_s = time.perf_counter()
+            for T in range(1, n_pt + 1):
+                toks = [int(t) for t in model.sample(T, toks, 0.8, seed=a.seed)]
+            pt_wall = time.perf_counter() - t_s
+            sampled = {"temperature": 0.8, "device_loop_tokens_per_s": round(ppg * (ctx - 1) / s_wall, 1), "ms_per_generation": round(1e3 * s_wall, 3),
+                       "per_token_call_tokens_per_s": round(ppg * n_pt / pt_wall, 1), "per_token_positions": n_pt,
+                       "distinct_tokens_in_row_0": int(len(set(int(t) for t in ids_s[0]))),
+                       "how": "zg_gpt_generate_sample (sampler node in the captured decode step, uniforms from the library's counter PRNG) against a "
+                              "host loop over zg_gpt_sample; identical tokens for identical seeds (tests/test_sampled_generate_gpu.py)"}
+        except Exception as e:
+            sampled = {"error": str(e)}
     # BASELINE.json configs[2..4] on this GPU, one handle after another (the headline handle stays: its numbers are above)
     others = None
     if a.model == "124M" and world == 1 and ppg == 1 and not a.weights_f32 and not a.kv_f16 and not a.kv_b24 and not a.no_other_configs:
@@ -789,6 +813,7 @@ def main():
         },
         "mfma_gemm_768x3072": gemm,
         "prefill": prefill,
+        "sampled_generation": sampled,
         "other_configs": others,
         "device_time_s": round(dev_s, 4),
         "setup_s": round(setup_s, 2),

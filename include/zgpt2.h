@@ -203,6 +203,8 @@ enum {
                                       outside the tests' near-zero floor); bf16-weight handles only */
     ZG_GPT_NO_PREFETCH = 1 << 5, /* zg_gpt_generate_*: no side-stream L2 prefetcher beside the decode chain (results are
                                     identical either way; a measurement switch) */
+    ZG_GPT_SAMPLED_GENERATE = 1 << 7, /* capture the decode graphs of zg_gpt_generate_sample_* at create as well (otherwise they are
+                                      captured by the first sampled generation: the one place a generate call may allocate) */
     ZG_GPT_KV_B24 = 1 << 6       /* store the KV cache as 24-bit floats (the fp32 value rounded to 16 mantissa bits, kept as a
                                     bf16 plane + a plane of 8 more mantissa bits): 3/4 of the fp32 cache's traffic, 2^-17 per
                                     cached element — inside the 1e-3 parity bound at full context, unlike ZG_GPT_KV_F16 (which
@@ -314,6 +316,16 @@ int zg_gpt_generate_greedy(zg_gpt* g, const size_t* prompts, size_t prompt_strid
 int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride,
                             const size_t* prompt_lens, size_t n_steps);
 int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t out_len);
+/* generate AS THE REFERENCE RUNS IT (src/main.zig:322-342 with GPT.sample, :198-207, temp 0.8 in main): every token behind the prompt is
+ * drawn — softmax(logits / temp), first index whose running sum exceeds u x total — with the whole loop on the device (the sampler
+ * is a node of the captured decode step).  The reference re-seeds from the wall clock per token; here the uniform of (sequence b,
+ * position T) is the library's counter PRNG of (seed, T, b), the one zg_gpt_sample uses for uniforms == NULL: the call returns
+ * exactly the tokens of the host loop `tok = zg_gpt_sample(g, T, &tok, 1, temp, NULL, seed, ...)`, without a host round trip per
+ * token (4.x k instead of 2.6 k tokens/s at 124M).  Results through zg_gpt_generate_fetch. */
+int zg_gpt_generate_sample_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps,
+                                   float temp, uint64_t seed);
+int zg_gpt_generate_sample(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps, float temp,
+                           uint64_t seed, size_t* out_tokens, size_t out_len);
 /* The same for the prompts of several handles at once (handles on distinct streams: zg_gpt_create_ex): prompts is
  * [sum of the handles' batches, prompt_stride], rows in handle order, prompt_lens alike; every handle generates its own rows.
  * A graph launch returns only when its hardware queue has room, so the handles are fed by one short-lived feeder thread each

@@ -91,6 +91,8 @@ SIGNATURES = {
     "zg_gpt_generate_greedy": (C.c_int, [vp, vp, sz, vp, sz, vp, sz]),
     "zg_gpt_generate_enqueue": (C.c_int, [vp, vp, sz, vp, sz]),
     "zg_gpt_generate_fetch": (C.c_int, [vp, sz, vp, sz]),
+    "zg_gpt_generate_sample_enqueue": (C.c_int, [vp, vp, sz, vp, sz, C.c_float, C.c_uint64]),
+    "zg_gpt_generate_sample": (C.c_int, [vp, vp, sz, vp, sz, C.c_float, C.c_uint64, vp, sz]),
     "zg_gpt_time_kernel": (C.c_int, [vp, C.c_int, C.c_int, f32p, szp]),
     "zg_gpt_profile_step": (C.c_int, [vp, sz, C.c_int, f32p, sz]),
     "zg_debug_prefetch_stats": (C.c_int, [vp, vp, sz]),
@@ -103,6 +105,7 @@ SIGNATURES = {
 # flags / slots of include/zgpt2.h
 GPT_WEIGHTS_BF16, GPT_WEIGHTS_F32, GPT_NO_GRAPH, GPT_KV_F16, GPT_NO_PREFILL, GPT_PREFILL_2PLANE, GPT_NO_PREFETCH = 0, 1, 2, 4, 8, 16, 32
 GPT_KV_B24 = 64
+GPT_SAMPLED_GENERATE = 128
 BLOCK_SLOTS = ["ln_1_g", "ln_1_b", "c_attn_w", "c_attn_b", "c_proj_w", "c_proj_b",
                "ln_2_g", "ln_2_b", "c_fc_w", "c_fc_b", "mlp_proj_w", "mlp_proj_b"]
 TOP_SLOTS = ["wte", "wpe", "ln_f_g", "ln_f_b"]

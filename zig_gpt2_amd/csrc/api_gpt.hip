@@ -90,6 +90,13 @@ struct zg_gpt {
     // do not wait for the exact seq_len (which lives in device memory).
     std::vector<hipGraphExec_t> graphs;
     std::vector<hipGraphExec_t> graphs_k;  // per bucket: graph_steps consecutive steps with lm_head in one graph (generate loop)
+    // generate with the sampler (zg_gpt_generate_sample_*): per bucket one step / graph_steps steps with lm_head AND the sampler
+    // node behind it; captured at create with ZG_GPT_SAMPLED_GENERATE, otherwise on the first sampled generation
+    std::vector<hipGraphExec_t> graphs_s, graphs_ks;
+    int* sampled;             // [batch]: the sampler's draw from the last step's logits
+    SampleParams* samp;       // device: temperature and seed of the generation in flight
+    SampleParams* h_samp;     // pinned mirror
+    bool gen_sampled;         // the generation in flight draws its tokens
     size_t graph_steps;
     hipStream_t graph_stream;
     size_t steps_enqueued;
@@ -197,6 +204,8 @@ void carve(zg_gpt* g, char* wbase, char* sbase) {
     g->forced = (int*)P(B * 4);
     g->cur_token = (int*)P(B * 4);
     g->out_tokens = (int*)P(B * C * 4);
+    g->sampled = (int*)P(B * 4);
+    g->samp = (SampleParams*)P(sizeof(SampleParams));
     g->xp = (bf16_t*)P(E * 48);
     g->hp = (bf16_t*)P(4 * E * 48);
     g->ap = (bf16_t*)P(E * 48);
@@ -290,6 +299,7 @@ EmbedArgs embed_args(const zg_gpt* g, int finish_only) {
     e.st_out = g->st_on ? g->xst : nullptr;
     e.finish_only = finish_only;
     e.progress = g->pf_on ? &g->pf_ctl->progress : nullptr;
+    e.sampled = g->sampled;
     return e;
 }
 
@@ -389,7 +399,7 @@ int ensure_ln_folded(zg_gpt* g, hipStream_t s) {
 int env_int(const char* name, int dflt);
 
 int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf* prof = nullptr, int only = -1, size_t only_layer = 0,
-                 std::vector<PfJob>* rec = nullptr, int salt = -1) {
+                 std::vector<PfJob>* rec = nullptr, int salt = -1, bool with_sampler = false) {
     const size_t E = g->cfg.n_embed;
     auto launch_id = [&](size_t l, int k) { return (unsigned)(salt >= 0 ? 1 + (2 * salt + k) % 254 : 2 * (int)l + 1 + k); };
     ZG_TRY(prof_mark(prof, -1, s));
@@ -540,6 +550,9 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
         ZG_TRY(enqueue_lm_head(g, s, rec));
         ZG_TRY(prof_mark(prof, 6, s));
     }
+    // GPT.sample's tail (main.zig:200-206) on the logits of this step: the next step's embed kernel feeds what it draws (mode 2)
+    if (with_sampler && with_logits && only < 0 && !rec)
+        ZG_TRY(launch_sample_step(g->logits, (int)g->batch, (int)g->cfg.vocab_size, g->samp, g->ctrl, g->sampled, s));
     return ZG_OK;
 }
 
@@ -732,7 +745,7 @@ int pf_stop(zg_gpt* g, hipStream_t s) {
 size_t prefill_min() { return 4; }  // shorter prompts go through the decode chain (measured: the whole-prompt pass pays from 4 tokens up)
 
 void drop_graphs(zg_gpt* g) {
-    for (auto* v : {&g->graphs, &g->graphs_k})
+    for (auto* v : {&g->graphs, &g->graphs_k, &g->graphs_s, &g->graphs_ks})
         for (auto& e : *v)
             if (e) {
                 (void)hipGraphExecDestroy(e);
@@ -743,11 +756,11 @@ void drop_graphs(zg_gpt* g) {
 // Run one decode step at sequence length seq_len: replay the graph of its bucket (capturing it on
 // first use), or launch eagerly when graphs are disabled / the stream cannot be captured.
 // n_steps consecutive steps captured on stream cs into *out
-int capture_steps(zg_gpt* g, hipGraphExec_t* out, bool with_logits, int t_hi, size_t n_steps, hipStream_t cs) {
+int capture_steps(zg_gpt* g, hipGraphExec_t* out, bool with_logits, int t_hi, size_t n_steps, hipStream_t cs, bool with_sampler = false) {
     hipGraph_t graph = nullptr;
     ZG_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int st = ZG_OK;
-    for (size_t i = 0; i < n_steps && st == ZG_OK; ++i) st = enqueue_step(g, with_logits, t_hi, cs);
+    for (size_t i = 0; i < n_steps && st == ZG_OK; ++i) st = enqueue_step(g, with_logits, t_hi, cs, nullptr, -1, 0, nullptr, -1, with_sampler);
     hipError_t e = hipStreamEndCapture(cs, &graph);
     if (st != ZG_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -777,6 +790,14 @@ int capture_multi(zg_gpt* g, size_t b, hipStream_t s) {
     return capture_steps(g, &g->graphs_k[b], true, t_hi, g->graph_steps, s);
 }
 
+// The sampled twins of a bucket's graphs (one step / graph_steps steps, each with lm_head and the sampler node).
+int capture_sampled(zg_gpt* g, size_t b, bool multi, hipStream_t s) {
+    auto& v = multi ? g->graphs_ks : g->graphs_s;
+    if (v.size() <= b) v.resize(b + 1, nullptr);
+    if (v[b]) return ZG_OK;
+    return capture_steps(g, &v[b], true, bucket_t_hi(g, (b + 1) * 64), multi ? g->graph_steps : 1, s, true);
+}
+
 // All decode graphs of a handle (two per 64-position bucket: with / without lm_head) for stream s.  Called from
 // zg_gpt_create — the State.init moment (main.zig:46-64) — so that no forward allocates; a later zg_set_stream
 // re-captures them on the first call that sees the new stream.
@@ -790,16 +811,28 @@ int capture_all(zg_gpt* g, hipStream_t s) {
     for (size_t idx = 0; idx < n; ++idx) ZG_TRY(capture_bucket(g, idx, s));
     if (g->graph_steps > 1)
         for (size_t b = 0; b < n / 2; ++b) ZG_TRY(capture_multi(g, b, s));
+    if (g->flags & ZG_GPT_SAMPLED_GENERATE)
+        for (size_t b = 0; b < n / 2; ++b) {
+            ZG_TRY(capture_sampled(g, b, false, s));
+            if (g->graph_steps > 1) ZG_TRY(capture_sampled(g, b, true, s));
+        }
     return ZG_OK;
 }
 
 // Run one decode step at sequence length seq_len: replay the graph of its bucket, or launch eagerly when graphs
 // are disabled / the stream cannot be captured.
-int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s) {
+int run_step(zg_gpt* g, bool with_logits, size_t seq_len, hipStream_t s, bool with_sampler = false) {
     ZG_TRY(ensure_ln_folded(g, s));
     const int t_hi = bucket_t_hi(g, seq_len);
-    if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_step(g, with_logits, t_hi, s);
+    with_sampler = with_sampler && with_logits;
+    if ((g->flags & ZG_GPT_NO_GRAPH) || s == nullptr) return enqueue_step(g, with_logits, t_hi, s, nullptr, -1, 0, nullptr, -1, with_sampler);
     if (g->graph_stream != s) ZG_TRY(capture_all(g, s));  // the caller switched streams after zg_gpt_create
+    if (with_sampler) {
+        const size_t b = (seq_len + 63) / 64 - 1;
+        ZG_TRY(capture_sampled(g, b, false, s));
+        ZG_HIP(hipGraphLaunch(g->graphs_s[b], s));
+        return ZG_OK;
+    }
     const size_t idx = ((seq_len + 63) / 64 - 1) * 2 + (with_logits ? 1 : 0);
     ZG_TRY(capture_bucket(g, idx, s));  // no-op: captured at create
     ZG_HIP(hipGraphLaunch(g->graphs[idx], s));
@@ -979,7 +1012,9 @@ int zg_gpt_create_ex(zg_gpt** out, const zg_gpt_config* config, size_t batch, un
         delete g;
         return hip_fail(he, "hipHostMalloc(control mirrors)", __FILE__, __LINE__);
     }
-    static_assert(sizeof(StepCtrl) <= 256, "the fault word sits 256 bytes behind the control mirror");
+    static_assert(sizeof(StepCtrl) + sizeof(SampleParams) <= 256, "the fault word sits 256 bytes behind the control mirror");
+    g->h_samp = reinterpret_cast<SampleParams*>(reinterpret_cast<char*>(g->h_ctrl) + 128);  // (same pinned block)
+    g->gen_sampled = false;
     g->fault = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(g->h_ctrl) + 256);
     *g->fault = 0;
     g->steps_enqueued = 0;
@@ -1298,7 +1333,8 @@ int zg_gpt_hidden(zg_gpt* g, float* x_out, size_t len) {
 // gen_pump — ONE graph launch (graph_steps decode steps) or one single step, false when nothing is left; gen_end — the
 // prefetcher's stop word and the record of the last pick.  After a successful gen_begin, gen_end must run (also on failure:
 // the prefetcher must not wait for steps that never come).
-static int gen_begin(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps) {
+static int gen_begin(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps, bool sampled = false,
+                     float temp = 1.0f, uint64_t seed = 0) {
     ZG_REQUIRE(g && prompts && prompt_lens, ZG_ERR_ARG, "generate: null argument");
     const size_t C = g->cfg.context_size, V = g->cfg.vocab_size, B = g->batch;
     ZG_REQUIRE(n_steps >= 1 && n_steps <= C, ZG_ERR_SHAPE, "generate: n_steps %zu outside 1..%zu", n_steps, C);
@@ -1324,8 +1360,15 @@ static int gen_begin(zg_gpt* g, const size_t* prompts, size_t prompt_stride, con
         first = min_prompt < n_steps ? min_prompt : n_steps;
     g->h_ctrl->step = (int)first;
     g->h_ctrl->seq_len = (int)first;
-    g->h_ctrl->mode = 0;
+    g->h_ctrl->mode = sampled ? 2 : 0;
     g->h_ctrl->n_partials = g->lm_grid;
+    g->gen_sampled = sampled;
+    if (sampled) {
+        g->h_samp->inv_temp = 1.0f / temp;
+        g->h_samp->pad = 0;
+        g->h_samp->seed = seed;
+        ZG_HIP(hipMemcpyAsync(g->samp, g->h_samp, sizeof(SampleParams), hipMemcpyHostToDevice, s));
+    }
     ZG_HIP(hipMemcpyAsync(g->prompt, g->h_ints, B * C * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->prompt_len, g->h_ints + B * C, B * sizeof(int), hipMemcpyHostToDevice, s));
     ZG_HIP(hipMemcpyAsync(g->ctrl, g->h_ctrl, sizeof(StepCtrl), hipMemcpyHostToDevice, s));
@@ -1362,11 +1405,16 @@ static int gen_pump(zg_gpt* g, bool* more) {
     if (K > 1 && st >= g->gen_min_prompt && st % K == 0 && st + K <= n_steps && st + K <= C) {
         if (g->graph_stream != s) ZG_TRY(capture_all(g, s));
         const size_t b = st / 64;  // sequence lengths st + 1 .. st + K share a bucket (K divides 64)
-        ZG_TRY(capture_multi(g, b, s));
-        ZG_HIP(hipGraphLaunch(g->graphs_k[b], s));
+        if (g->gen_sampled) {
+            ZG_TRY(capture_sampled(g, b, true, s));
+            ZG_HIP(hipGraphLaunch(g->graphs_ks[b], s));
+        } else {
+            ZG_TRY(capture_multi(g, b, s));
+            ZG_HIP(hipGraphLaunch(g->graphs_k[b], s));
+        }
         g->gen_pos = st + K;
     } else {
-        ZG_TRY(run_step(g, st >= g->gen_min_prompt, st + 1, s));
+        ZG_TRY(run_step(g, st >= g->gen_min_prompt, st + 1, s, g->gen_sampled));
         g->gen_pos = st + 1;
     }
     *more = g->gen_pos < n_steps;
@@ -1390,6 +1438,29 @@ int zg_gpt_generate_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stri
     int rs = ZG_OK;
     for (bool more = true; more && rs == ZG_OK;) rs = gen_pump(g, &more);
     return gen_end(g, rs);
+}
+
+// generate (src/main.zig:322-342) AS THE REFERENCE RUNS IT: every token behind the prompt is drawn by GPT.sample
+// (main.zig:198-207, :336-338) — softmax(logits / temp), then the first index whose running sum exceeds u x total — with the
+// whole loop on the device: the sampler is a node of the captured decode step (sample_step_kernel) and the next step's embed
+// kernel feeds its draw.  The uniform of (sequence b, position T) is the counter PRNG of (seed, T, b) that zg_gpt_sample uses when
+// it is given no uniforms, so this call returns exactly the tokens of a host loop `tok = zg_gpt_sample(g, T, tok, temp, NULL,
+// seed, ...)` — without a host round trip per token.  Results through zg_gpt_generate_fetch.
+int zg_gpt_generate_sample_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps,
+                                   float temp, uint64_t seed) {
+    ZG_TRY(require_init());
+    ZG_REQUIRE(temp > 0.0f, ZG_ERR_ARG, "generate_sample: temperature %f", temp);
+    ZG_TRY(gen_begin(g, prompts, prompt_stride, prompt_lens, n_steps, true, temp, seed));
+    int rs = ZG_OK;
+    for (bool more = true; more && rs == ZG_OK;) rs = gen_pump(g, &more);
+    return gen_end(g, rs);
+}
+
+int zg_gpt_generate_sample(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps, float temp,
+                           uint64_t seed, size_t* out_tokens, size_t out_len) {
+    ZG_REQUIRE(g && out_tokens && out_len >= g->batch * n_steps, ZG_ERR_SHAPE, "generate_sample: out_tokens too short");
+    ZG_TRY(zg_gpt_generate_sample_enqueue(g, prompts, prompt_stride, prompt_lens, n_steps, temp, seed));
+    return zg_gpt_generate_fetch(g, n_steps, out_tokens, out_len);
 }
 
 // generate (src/main.zig:322-342) for the prompts of SEVERAL handles at once: independent sequences need not run in lock step

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         const int p_cur = a.prompt[(size_t)b * a.prompt_stride + min(s, a.prompt_stride - 1)];
         const int p_last = a.prompt[(size_t)b * a.prompt_stride + max(min(np, a.prompt_stride) - 1, 0)];
         const int forced = a.forced[b];
+        const int drawn = a.sampled[b];  // (mode 2; always a readable address)
         // argmax over the wave: DPP row rotations inside the 16-lane rows, then the four row winners through v_readlane
         // (six rounds of ds_bpermute pairs were ~0.3 us of dependent LDS-crossbar hops)
 #define ZG_AM_STEP(N)                                                                                                   \
@@ -306,9 +307,10 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
         // logits that are all NaN compare false everywhere and leave the start value standing: index 0 then, as a loop that starts at
         // logits[0] and keeps what compares greater (the oracle, and the reference's order of comparison) — never an index past
         // the vocabulary, which the gather below would follow out of the table (a NaN in a checkpoint must not fault the GPU)
-        const int g = (unsigned)bi < (unsigned)a.vocab ? bi : 0;
-        // the greedy pick of step s-1 exists iff that step ran lm_head (main.zig:337)
-        const bool have_pick = a.finish_only == 2 || ((mode == 0) && (s >= 1) && (s - 1 >= np));
+        int g = (unsigned)bi < (unsigned)a.vocab ? bi : 0;
+        if (mode == 2 && a.finish_only != 2) g = (unsigned)drawn < (unsigned)a.vocab ? drawn : 0;  // the sampler's draw takes the pick's place
+        // the pick of step s-1 exists iff that step ran lm_head (main.zig:337)
+        const bool have_pick = a.finish_only == 2 || ((mode != 1) && (s >= 1) && (s - 1 >= np));
         if (lane == 0) {
             if (have_pick) {
                 if (a.finish_only == 2) a.cur_token[b] = g;  // zg_gpt_argmax
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
                 else if (s < np) tok = p_cur;      // main.zig:331-334: prompt token s
                 else if (s == np) tok = p_last;    // main.zig:337: the previous token is fed again
                 else tok = g;
-                if (mode == 0 && s < np) a.out_tokens[(size_t)b * a.out_stride + s] = tok;
+                if (mode != 1 && s < np) a.out_tokens[(size_t)b * a.out_stride + s] = tok;
                 a.cur_token[b] = tok;
                 s_tok[b] = tok;
             }
@@ -370,59 +372,113 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
     }
 }
 
+// softmax(x / temp) and the weighted draw of GPT.sample (src/main.zig:200-206; std.rand weightedIndex: the first index whose
+// running sum exceeds u x total) for ONE row by a workgroup of 1024 lanes.  Every global access is coalesced (the first version
+// gave each lane a contiguous chunk of 50 logits — 1024 scattered streams — and scanned 1024 partial sums on one lane: ~100 us per
+// row at V = 50257).  The running sum keeps index order at the level that decides the draw: a wave sums SEGMENTS of 64 consecutive
+// elements (786 at V = 50257), one wave walks the segment sums in order — 64 lanes x consecutive runs of segments, a wave scan
+// over the lanes, the owning lane walks its run — and the segment that holds the point is scanned lane by lane.  Sums inside a
+// segment and over lanes are tree-shaped: the draw can differ from a strictly left-to-right sum only where u x total lies within
+// rounding (~1e-7) of a boundary.  WRITE: leave the probabilities in x, as the reference leaves them in state.logits.
+// Returns the draw (every lane); NaN probabilities (no interval holds the point) give the last index.  vocab <= 64 x 4096.
+template <bool WRITE>
+__device__ __forceinline__ int sample_row(float* x, int vocab, float inv_temp, float u, float* s_red, float* s_seg, int* s_pick) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -3.0e38f;
+    for (int i = tid; i < vocab; i += 1024) mx = fmaxf(mx, x[i] * inv_temp);
+    mx = block_allmax(mx, s_red);
+    const int nseg = (vocab + 63) >> 6;
+    float wsum = 0.0f;
+    for (int seg = wave; seg < nseg; seg += 16) {
+        const int i = seg * 64 + lane;
+        const float e = i < vocab ? __expf(x[i] * inv_temp - mx) : 0.0f;
+        const float sg = wave_allsum(e);
+        if (lane == 0) s_seg[seg] = sg;
+        wsum += sg;
+    }
+    const float total = block_allsum(lane == 0 ? wsum : 0.0f, s_red);  // (also the barrier behind s_seg)
+    const float inv = 1.0f / total;
+    if (tid == 0) *s_pick = vocab - 1;
+    __syncthreads();
+    if (wave == 0) {
+        const float point = u * total;
+        const int run = (nseg + 63) >> 6, s0 = lane * run, s1 = min(s0 + run, nseg);
+        float local = 0.0f;
+        for (int k = s0; k < s1; ++k) local += s_seg[k];
+        float incl = local;  // inclusive scan over the lanes, in lane order
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(s0 < s1 && point < incl);
+        if (hit != 0ull) {
+            const int owner = __builtin_ctzll(hit);
+            // the owning lane walks its run of segments; all lanes follow the same scalar path afterwards
+            int seg = 0;
+            float before = 0.0f;
+            if (lane == owner) {
+                before = incl - local;
+                seg = s1 - 1;
+                for (int k = s0; k < s1; ++k) {
+                    if (point < before + s_seg[k]) {
+                        seg = k;
+                        break;
+                    }
+                    before += s_seg[k];
+                }
+            }
+            seg = __shfl(seg, owner, 64);
+            before = __shfl(before, owner, 64);
+            const int i = seg * 64 + lane;
+            float e = 0.0f;
+            if (i < vocab) e = __expf(x[i] * inv_temp - mx);  // (x still holds the logits: the probabilities are written last)
+            float c = e;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float up = __shfl_up(c, off, 64);
+                if (lane >= off) c += up;
+            }
+            const unsigned long long in = __builtin_amdgcn_ballot_w64(i < vocab && point < before + c);
+            // (rounding between the segment sum and its lane-by-lane scan can leave the point just past the last lane: that lane then)
+            const int l = in != 0ull ? __builtin_ctzll(in) : min(63, vocab - 1 - seg * 64);
+            if (lane == 0) *s_pick = seg * 64 + l;
+        }
+    }
+    __syncthreads();
+    if (WRITE)  // every lane rewrites only elements it alone reads here: no ordering between lanes needed
+        for (int i = tid; i < vocab; i += 1024) x[i] = __expf(x[i] * inv_temp - mx) * inv;
+    return *s_pick;
+}
+
 // Sampler tail of GPT.sample (src/main.zig:200-206): one workgroup per sequence, in place on its logits
 // row: p = softmax(logits / temp); token = first index whose running sum of p exceeds u * sum(p).
 __global__ __launch_bounds__(1024) void sample_kernel(float* logits, int vocab, float inv_temp, const float* u,
                                                       int* token_out) {
     __shared__ float s_red[16];
-    __shared__ float s_scan[1024];
-    float* x = logits + (size_t)blockIdx.x * vocab;
-    const int tid = threadIdx.x;
-    float mx = -3.0e38f;
-    for (int i = tid; i < vocab; i += 1024) mx = fmaxf(mx, x[i] * inv_temp);
-    mx = block_allmax(mx, s_red);
-    // each thread owns a contiguous chunk so that the running sum follows index order
-    const int chunk = (vocab + 1023) / 1024, lo = tid * chunk, hi = min(lo + chunk, vocab);
-    float local = 0.0f;
-    for (int i = lo; i < hi; ++i) {
-        const float e = __expf(x[i] * inv_temp - mx);
-        x[i] = e;
-        local += e;
-    }
-    const float total = block_allsum(local, s_red);
-    const float inv = 1.0f / total;
-    for (int i = lo; i < hi; ++i) x[i] *= inv;  // probabilities, like the reference leaves in state.logits
-    local *= inv;
-    s_scan[tid] = local;
-    __syncthreads();
-    if (tid == 0) {  // 1024 partial sums: a serial scan keeps the reference's left-to-right order
-        float acc = 0.0f;
-        for (int t = 0; t < 1024; ++t) {
-            const float v = s_scan[t];
-            s_scan[t] = acc;  // exclusive prefix
-            acc += v;
-        }
-        s_red[0] = acc;
-    }
-    __syncthreads();
-    const float point = u[blockIdx.x] * s_red[0];
-    const float before = s_scan[tid];
-    const bool last = lo < hi && hi == vocab;  // the thread owning the final chunk also catches point >= total
-    if (lo < hi && point >= before && (point < before + local || last)) {
-        float acc = before;
-        int pick = hi - 1;
-        for (int i = lo; i < hi; ++i) {
-            acc += x[i];
-            if (point < acc) {
-                pick = i;
-                break;
-            }
-        }
-        atomicMin(&token_out[blockIdx.x], pick);
-    }
-    // probabilities that are NaN put the point in no thread's interval: the last index then, like a point at or past the total
-    __syncthreads();
-    if (tid == 0 && (unsigned)__hip_atomic_load(&token_out[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)vocab) token_out[blockIdx.x] = vocab - 1;
+    __shared__ float s_seg[4096];
+    __shared__ int s_pick;
+    const int pick = sample_row<true>(logits + (size_t)blockIdx.x * vocab, vocab, inv_temp, u[blockIdx.x], s_red, s_seg, &s_pick);
+    if (threadIdx.x == 0) token_out[blockIdx.x] = pick;
+}
+
+// The same tail inside a captured decode step (zg_gpt_generate_sample_*): temperature and seed from device memory, the uniform
+// of (sequence, position) from the counter PRNG zg_gpt_sample uses for uniforms == NULL (splitmix64 finaliser, 24 random bits),
+// the atomicMin target armed by the kernel itself.  One workgroup per sequence, in place on its logits row.
+__global__ __launch_bounds__(1024) void sample_step_kernel(float* logits, int vocab, const SampleParams* params, const StepCtrl* ctrl, int* token_out) {
+    __shared__ float s_red[16];
+    __shared__ float s_seg[4096];
+    __shared__ int s_pick;
+    // u of (seed, sequence length of the step whose logits these are, sequence): as zg_gpt_sample derives it on the host
+    unsigned long long z = params->seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)ctrl->seq_len * 0xD1B54A32D192ED03ULL + (unsigned long long)blockIdx.x + 1ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    const float u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-08f;
+    // (no probabilities written back: nobody reads the logits of a step in the loop; the draw itself is computed before that
+    // pass in zg_gpt_sample's kernel too — same tokens)
+    const int pick = sample_row<false>(logits + (size_t)blockIdx.x * vocab, vocab, params->inv_temp, u, s_red, s_seg, &s_pick);
+    if (threadIdx.x == 0) token_out[blockIdx.x] = pick;
 }
 
 inline int grid_for(size_t n, int block = 256, int cap = 2048) {
@@ -587,8 +643,15 @@ int launch_split3(const float* in, size_t rows, int K, bf16_t* out, hipStream_t 
 }
 
 int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s) {
-    ZG_HIP(hipMemsetAsync(token_out, 0x7f, batch * sizeof(int), s));  // atomicMin target
+    ZG_REQUIRE(vocab >= 1 && vocab <= 64 * 4096, ZG_ERR_UNSUPPORTED, "sampler: vocabulary of %d beyond 262144", vocab);
     hipLaunchKernelGGL(sample_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, 1.0f / temp, u, token_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int launch_sample_step(float* logits, int batch, int vocab, const SampleParams* params, const StepCtrl* ctrl, int* token_out, hipStream_t s) {
+    ZG_REQUIRE(vocab >= 1 && vocab <= 64 * 4096, ZG_ERR_UNSUPPORTED, "sampler: vocabulary of %d beyond 262144", vocab);
+    hipLaunchKernelGGL(sample_step_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, params, ctrl, token_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

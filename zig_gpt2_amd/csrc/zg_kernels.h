@@ -284,8 +284,18 @@ struct EmbedArgs {
     float* st_out;           // optional LayerNorm statistics by tile of x (GemvArgs.st_in): [8][n_embed / 16][2]
     int finish_only;         // 1: only record the greedy pick of the last step; 2: argmax -> cur_token
     unsigned* progress;      // set to (T << 8) | 1 (and the XCD of this block beside it) when a step starts; the other decode kernels add 1 each
+    const int* sampled;      // [B] (mode 2: generate with the sampler) the token sample_step_kernel drew from the previous step's logits
 };
 int launch_embed_step(const EmbedArgs& a, hipStream_t s);
+// GPT.sample's tail (src/main.zig:200-206) inside the generate loop: temperature and seed live in device memory (one captured
+// graph serves every call), the uniform of (sequence b, position T) is the library's counter PRNG of (seed, T, b) — what
+// zg_gpt_sample uses when it is given no uniforms
+struct SampleParams {
+    float inv_temp;
+    unsigned pad;
+    unsigned long long seed;
+};
+int launch_sample_step(float* logits, int batch, int vocab, const SampleParams* params, const StepCtrl* ctrl, int* token_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ multi-GPU (dist.hip)
 int dist_broadcast(void* buf, size_t bytes, int root, hipStream_t s);  // in place, over the communicator of zg_dist_init

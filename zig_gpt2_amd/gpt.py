@@ -17,7 +17,8 @@ from .synth import GPTConfig
 
 class GPT:
     def __init__(self, config: GPTConfig, batch=1, weights_f32=False, use_graph=True, kv_f16=False, prefill=True,
-                 prefill_planes=3, prefetch=True, kv_b24=False, share_weights_with=None, own_stream=False, stream_priority=0):
+                 prefill_planes=3, prefetch=True, kv_b24=False, share_weights_with=None, own_stream=False, stream_priority=0,
+                 sampled_generate=False):
         """share_weights_with / own_stream / stream_priority: zg_gpt_options of zg_gpt_create_ex (a handle of an independent
         prompt group on the same GPU: private stream, weight region borrowed from another GPT of the same config)."""
         self.config, self.batch = config, batch
@@ -28,6 +29,7 @@ class GPT:
         flags |= 0 if prefill else _lib.GPT_NO_PREFILL
         flags |= _lib.GPT_PREFILL_2PLANE if prefill_planes == 2 else 0
         flags |= 0 if prefetch else _lib.GPT_NO_PREFETCH
+        flags |= _lib.GPT_SAMPLED_GENERATE if sampled_generate else 0
         cfg = _lib.GptConfig(config.vocab_size, config.context_size, config.n_layer, config.n_heads, config.n_embed)
         h = C.c_void_p()
         if share_weights_with is None and not own_stream:
@@ -156,6 +158,18 @@ class GPT:
         out = np.zeros((self.batch, n_steps), np.uint64)
         check(self._L.zg_gpt_generate_fetch(self.h, n_steps, ptr(out), out.size))
         return out
+
+    def generate_sample(self, prompts, n_steps, temp, seed=0):
+        """generate (src/main.zig:322-342) as the reference runs it — every token behind the prompt drawn by GPT.sample — with the
+        loop on the device; the tokens of the host loop over `sample(T, tok, temp, seed=seed)`."""
+        mat, lens, stride = self._prompts(prompts)
+        out = np.zeros((self.batch, n_steps), np.uint64)
+        check(self._L.zg_gpt_generate_sample(self.h, ptr(mat), stride, ptr(lens), n_steps, temp, seed, ptr(out), out.size))
+        return out
+
+    def generate_sample_enqueue(self, prompts, n_steps, temp, seed=0):
+        mat, lens, stride = self._prompts(prompts)
+        check(self._L.zg_gpt_generate_sample_enqueue(self.h, ptr(mat), stride, ptr(lens), n_steps, temp, seed))
 
     PROFILE_CLASSES = ["embed", "ln1_c_attn_kv", "attention", "merge_attn_proj_resid", "ln2_c_fc_gelu",
                        "mlp_proj_resid", "lnf_lm_head_argmax", "step_total"]
