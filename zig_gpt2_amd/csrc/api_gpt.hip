@@ -1201,8 +1201,8 @@ int zg_gpt_step_bytes(zg_gpt* g, size_t seq_len, size_t* weight_bytes, size_t* k
     return ZG_OK;
 }
 
-int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens, int compute_logits,
-                   float* logits_out, size_t logits_len) {
+// GPT.forward enqueued on the handle's stream, nothing drained (zg_gpt_forward drains; zg_gpt_sample puts its sampler behind it first)
+static int forward_enqueue(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens, int compute_logits, float* logits_out, size_t logits_len) {
     ZG_TRY(require_init());
     ZG_REQUIRE(g && tokens, ZG_ERR_ARG, "gpt_forward: null argument");
     ZG_REQUIRE(n_tokens == g->batch, ZG_ERR_SHAPE, "gpt_forward: %zu tokens for batch %zu", n_tokens, g->batch);
@@ -1230,8 +1230,14 @@ int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tok
         ZG_HIP(hipMemcpyAsync(logits_out, g->logits, g->batch * V * sizeof(float),
                               is_device_ptr(logits_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     }
+    return ZG_OK;
+}
+
+int zg_gpt_forward(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_tokens, int compute_logits,
+                   float* logits_out, size_t logits_len) {
+    ZG_TRY(forward_enqueue(g, seq_len, tokens, n_tokens, compute_logits, logits_out, logits_len));
     // h_ints / h_ctrl are reused by the next call: drain before returning.
-    ZG_HIP(hipStreamSynchronize(s));
+    ZG_HIP(hipStreamSynchronize(gs(g)));
     return check_fault(g);
 }
 
@@ -1291,12 +1297,14 @@ int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_toke
     ZG_REQUIRE(g && tokens && tokens_out && temp > 0.0f, ZG_ERR_ARG, "gpt_sample: bad argument");
     const size_t V = g->cfg.vocab_size, B = g->batch;
     ZG_REQUIRE(!probs_out || probs_len >= B * V, ZG_ERR_SHAPE, "gpt_sample: probs_out needs %zu elements", B * V);
-    ZG_TRY(zg_gpt_forward(g, seq_len, tokens, n_tokens, 1, nullptr, 0));  // main.zig:199
+    for (size_t b = 0; uniforms && b < B; ++b)  // (checked before anything is enqueued)
+        ZG_REQUIRE(uniforms[b] >= 0.0f && uniforms[b] < 1.0f, ZG_ERR_ARG, "gpt_sample: uniform %f outside [0,1)", uniforms[b]);
+    ZG_TRY(forward_enqueue(g, seq_len, tokens, n_tokens, 1, nullptr, 0));  // main.zig:199 (not drained: the sampler goes behind it)
     hipStream_t s = gs(g);
-    float* h_u = reinterpret_cast<float*>(g->h_ints);
+    // (pinned, 320 bytes into the control block: h_ints[0 .. B) is still being read by the forward's token upload)
+    float* h_u = reinterpret_cast<float*>(reinterpret_cast<char*>(g->h_ctrl) + 320);
     for (size_t b = 0; b < B; ++b) {
         if (uniforms) {
-            ZG_REQUIRE(uniforms[b] >= 0.0f && uniforms[b] < 1.0f, ZG_ERR_ARG, "gpt_sample: uniform %f outside [0,1)", uniforms[b]);
             h_u[b] = uniforms[b];
         } else {  // counter PRNG (splitmix64 finaliser, 24 random bits), same construction as the synthetic weights
             uint64_t z = seed * 0x9E3779B97F4A7C15ULL + (uint64_t)seq_len * 0xD1B54A32D192ED03ULL + b + 1;
@@ -1314,6 +1322,7 @@ int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_toke
         ZG_HIP(hipMemcpyAsync(probs_out, g->logits, B * V * sizeof(float),
                               is_device_ptr(probs_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     ZG_HIP(hipStreamSynchronize(s));
+    ZG_TRY(check_fault(g));
     for (size_t b = 0; b < B; ++b) tokens_out[b] = (size_t)g->h_ints[B + b];
     return ZG_OK;
 }
