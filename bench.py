@@ -390,10 +390,10 @@ def groups_table(seed, n_prompts=8, group_counts=(1, 2, 4, 8)):
     — against the lock-step batch (G = 1): one row per G, ids compared row for row with G = 1.  Measured in every run because the
     answer decides the per-GPU load of --gpus N: co-running loses at every G (the chip overlaps two chains by a factor 1.6-2.4,
     the lock-step batch packs eight into 1.4 x the time of one), so the load stays one lock-step handle.
-    Runs tools/experiments/corun_ab.py as a CHILD process: how well two hardware queues overlap depends on the queue population
-    of the process — after this program's own earlier work (a second handle created beside the headline one) the same table
-    reads 2.2 ms per step round at G = 2 instead of 0.35 (profiles/NOTEBOOK.md §5) — so the table is taken where a user of
-    GPTGroups would take it: in a process that does nothing else."""
+    Runs tools/experiments/corun_ab.py as a CHILD process, BEFORE this process touches the GPU: how well hardware queues overlap
+    depends on who else holds queues on the device — inside this program, after its own earlier work, the same table has read
+    2.2 ms per step round at G = 2 instead of 0.35 (profiles/NOTEBOOK.md §5.1) — so the table is taken where a user of GPTGroups
+    would take it: on a device that does nothing else."""
     import subprocess
 
     exe = os.path.join(ROOT, "tools", "experiments", "corun_ab.py")
@@ -440,6 +440,28 @@ def main():
         sys.exit(2)
     if a.dry_run:
         return dry_run(a, rank, world)
+    # The two measurements that run as CHILD processes are taken first, while this process holds no GPU queue: both are sensitive
+    # to who else has queues on the device (the co-running groups: DESIGN §3.3; the op tier polls a completion word behind every
+    # call — under a parent with a dozen idle queues it has read 600 tok/s where it reads 770-850 alone).
+    early = {}
+    if world == 1 and a.gpus == 1:
+        from zig_gpt2_amd import synth as _synth
+
+        cfg0 = _synth.CONFIGS[a.model]
+        ctx0 = a.ctx or cfg0.context_size
+        ppg0 = a.prompts_per_gpu or 1
+        if not a.no_op_tier and a.model in ("124M", "nano-char", "tiny") and not a.weights_f32:
+            try:
+                early["op_tier"] = op_tier(a.model, a.seed, _synth.rand_tokens(1000 + a.seed * 131, 1, cfg0.vocab_size), ctx0, None)
+            except Exception as e:
+                early["op_tier"] = {"error": str(e)}
+        if a.model == "124M" and ppg0 == 1 and not a.weights_f32 and not a.kv_f16 and not a.kv_b24 and not a.no_other_configs:
+            try:
+                t_o = time.perf_counter()
+                early["groups"] = {"workload": "124M, 8 prompts on one GPU as G co-running groups (table)", "groups_on_one_gpu": groups_table(a.seed + 7),
+                                   "seconds_spent": round(time.perf_counter() - t_o, 1)}
+            except Exception as e:
+                early["groups"] = {"workload": "124M, 8 prompts as G groups", "error": str(e)}
     import torch
 
     from zig_gpt2_amd import _lib, gpt, shard, synth
@@ -745,12 +767,8 @@ def main():
                 others.append(o)
             except Exception as e:
                 others.append({"workload": f"{mname} x {mp}", "error": str(e)})
-        try:
-            t_o = time.perf_counter()
-            others.append({"workload": "124M, 8 prompts on one GPU as G co-running groups (table)", "groups_on_one_gpu": groups_table(a.seed + 7),
-                           "seconds_spent": round(time.perf_counter() - t_o, 1)})
-        except Exception as e:
-            others.append({"workload": "124M, 8 prompts as G groups", "error": str(e)})
+        if "groups" in early:
+            others.append(early["groups"])
         _lib.check(lib.zg_set_stream(stream.cuda_stream))
     # whole-step view: algorithmic bytes of all ctx steps / device time
     kv_total = sum(kv_elem * 2 * t * cfg.n_embed * cfg.n_layer * ppg for t in range(1, ctx + 1))
@@ -824,13 +842,12 @@ def main():
     }
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, weights, prompts[0], a.cpu_seconds)
-    if world == 1 and not a.no_op_tier and a.model in ("124M", "nano-char", "tiny") and not a.weights_f32:
-        try:
-            out["op_tier"] = op_tier(a.model, a.seed, prompts[0], ctx, out.get("cpu_baseline", {}).get("value"))
-            if "first_tokens" in out["op_tier"]:  # same weights, same prompt: the literal drop-in and the model tier agree
-                out["op_tier"]["tokens_equal_model_tier"] = out["op_tier"]["first_tokens"] == out["first_tokens"]
-        except Exception as e:
-            out["op_tier"] = {"error": str(e)}
+    if "op_tier" in early:
+        out["op_tier"] = early["op_tier"]
+        if "first_tokens" in out["op_tier"]:  # same weights, same prompt: the literal drop-in and the model tier agree
+            out["op_tier"]["tokens_equal_model_tier"] = out["op_tier"]["first_tokens"] == out["first_tokens"]
+            cpu_v = out.get("cpu_baseline", {}).get("value")
+            out["op_tier"]["vs_cpu_baseline"] = round(out["op_tier"]["value"] / cpu_v, 2) if cpu_v else None
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
