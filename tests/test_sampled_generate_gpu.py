@@ -66,6 +66,27 @@ def test_device_loop_equals_host_loop_over_the_per_token_sampler(zg, name, batch
             assert np.array_equal(got[b, : len(p)], p)
 
 
+def test_sampled_generation_behind_a_whole_prompt_pass(zg):
+    """A prompt long enough for the whole-prompt pass (zg_gpt_prefill inside generate): the draws behind it equal a host loop that
+    prefills the same prompt and then calls zg_gpt_sample per position."""
+    cfg = synth.CONFIGS["tiny3"]
+    w = synth.make_weights(cfg, seed=63, bf16=True)
+    prompts = [synth.rand_tokens(630 + b, 7, cfg.vocab_size) for b in range(2)]
+    n_steps, temp, seed = 40, 0.8, 31
+    m = zgpt.GPT(cfg, batch=2)
+    m.load_weights(w)
+    got = m.generate_sample(prompts, n_steps, temp, seed=seed)
+    m.prefill(np.stack(prompts), compute_logits=False)
+    want = np.zeros_like(got)
+    want[:, :7] = np.stack(prompts)
+    toks = [int(p[-1]) for p in prompts]  # main.zig:337: the last prompt token is fed again
+    for s in range(7, n_steps):
+        toks = [int(t) for t in m.sample(s + 1, toks, temp, seed=seed)]
+        want[:, s] = toks
+    m.close()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:4]
+
+
 def test_device_loop_against_the_oracle_sampler(zg):
     cfg = synth.CONFIGS["tiny3"]
     w = synth.make_weights(cfg, seed=62, bf16=True)
