@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPT.sample (src/main.zig:198-207: forward, logits / temp, softmax, an index drawn against the running sum) over random models,
 batches, temperatures and uniforms against the oracle: probabilities agree, the pick is the oracle's except where u * total
-lands within 1e-6 of a boundary of the running sum; both sides are fed the device's picks.  python tests/sweeps/sample.py [first_seed] [count]"""
+lands within 1e-6 of a boundary of the running sum; both sides are fed the device's picks.  Then the device loop
+(zg_gpt_generate_sample) against the host loop over the per-token call with the same seed: identical tokens.  python tests/sweeps/sample.py [first_seed] [count]"""
 import os, sys, traceback
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, os.path.join(root, "oracle"))
@@ -41,6 +42,23 @@ for seed in range(first, first + count):
                     near += 1
             toks = [int(t) for t in got]
         assert near <= max(2, steps * batch // 20), (what, near)
+        # the same model through the DEVICE loop (zg_gpt_generate_sample: sampler node in the captured step, uniforms from the counter
+        # PRNG of the seed) against the host loop over the per-token call with that seed: identical tokens
+        n_gen = min(cfg.context_size, steps + 8)
+        prompts = [synth.rand_tokens(9000 + 31 * seed + b, 1 + (seed + b) % 3, cfg.vocab_size) for b in range(batch)]
+        got = m.generate_sample(prompts, n_gen, temp, seed=seed)
+        want = np.zeros_like(got)
+        draws = [0] * batch
+        min_np = min(len(p) for p in prompts)
+        for s in range(n_gen):
+            fed = [int(p[s]) if s < len(p) else (int(p[-1]) if s == len(p) else int(draws[b])) for b, p in enumerate(prompts)]
+            if s >= min_np:
+                draws = m.sample(s + 1, fed, temp, seed=seed)
+            else:
+                m.forward(s + 1, fed, compute_logits=False)
+            for b, p in enumerate(prompts):
+                want[b, s] = fed[b] if s < len(p) else draws[b]
+        assert np.array_equal(got, want), (what, "device loop vs host loop", np.argwhere(got != want)[:3].tolist())
         m.close()
     except Exception:
         bad.append(seed)
