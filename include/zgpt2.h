@@ -321,7 +321,7 @@ int zg_gpt_generate_fetch(zg_gpt* g, size_t n_steps, size_t* out_tokens, size_t 
  * is a node of the captured decode step).  The reference re-seeds from the wall clock per token; here the uniform of (sequence b,
  * position T) is the library's counter PRNG of (seed, T, b), the one zg_gpt_sample uses for uniforms == NULL: the call returns
  * exactly the tokens of the host loop `tok = zg_gpt_sample(g, T, &tok, 1, temp, NULL, seed, ...)`, without a host round trip per
- * token (4.x k instead of 2.6 k tokens/s at 124M).  Results through zg_gpt_generate_fetch. */
+ * token (4.6 k tokens/s at 124M; the per-token call: 4.0 k).  Results through zg_gpt_generate_fetch. */
 int zg_gpt_generate_sample_enqueue(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps,
                                    float temp, uint64_t seed);
 int zg_gpt_generate_sample(zg_gpt* g, const size_t* prompts, size_t prompt_stride, const size_t* prompt_lens, size_t n_steps, float temp,

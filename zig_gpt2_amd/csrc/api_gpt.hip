@@ -94,6 +94,7 @@ struct zg_gpt {
     // node behind it; captured at create with ZG_GPT_SAMPLED_GENERATE, otherwise on the first sampled generation
     std::vector<hipGraphExec_t> graphs_s, graphs_ks;
     int* sampled;             // [batch]: the sampler's draw from the last step's logits
+    float* samp_ws;           // segment sums of the sampler (sample_workspace_floats)
     SampleParams* samp;       // device: temperature and seed of the generation in flight
     SampleParams* h_samp;     // pinned mirror
     bool gen_sampled;         // the generation in flight draws its tokens
@@ -206,6 +207,7 @@ void carve(zg_gpt* g, char* wbase, char* sbase) {
     g->out_tokens = (int*)P(B * C * 4);
     g->sampled = (int*)P(B * 4);
     g->samp = (SampleParams*)P(sizeof(SampleParams));
+    g->samp_ws = (float*)P(sample_workspace_floats((int)B) * 4);
     g->xp = (bf16_t*)P(E * 48);
     g->hp = (bf16_t*)P(4 * E * 48);
     g->ap = (bf16_t*)P(E * 48);
@@ -552,7 +554,8 @@ int enqueue_step(zg_gpt* g, bool with_logits, int t_hi, hipStream_t s, StepProf*
     }
     // GPT.sample's tail (main.zig:200-206) on the logits of this step: the next step's embed kernel feeds what it draws (mode 2)
     if (with_sampler && with_logits && only < 0 && !rec)
-        ZG_TRY(launch_sample_step(g->logits, (int)g->batch, (int)g->cfg.vocab_size, g->samp, g->ctrl, g->sampled, s));
+        ZG_TRY(launch_sample_step(g->logits, (int)g->batch, (int)g->cfg.vocab_size, g->samp, g->ctrl, g->part_val, g->lm_grid, g->lm_grid, g->samp_ws,
+                                  g->sampled, s));
     return ZG_OK;
 }
 
@@ -1316,7 +1319,8 @@ int zg_gpt_sample(zg_gpt* g, size_t seq_len, const size_t* tokens, size_t n_toke
     }
     float* d_u = g->q;  // scratch: q is dead after the forward
     ZG_HIP(hipMemcpyAsync(d_u, h_u, B * sizeof(float), hipMemcpyHostToDevice, s));
-    ZG_TRY(launch_sample(g->logits, (int)B, (int)V, temp, d_u, g->cur_token, s));  // main.zig:200-206
+    ZG_TRY(launch_sample(g->logits, (int)B, (int)V, temp, d_u, g->part_val, g->lm_grid, g->lm_grid, g->samp_ws, g->cur_token, probs_out != nullptr,
+                         s));  // main.zig:200-206
     ZG_HIP(hipMemcpyAsync(g->h_ints + B, g->cur_token, B * sizeof(int), hipMemcpyDeviceToHost, s));
     if (probs_out)
         ZG_HIP(hipMemcpyAsync(probs_out, g->logits, B * V * sizeof(float),

@@ -1,6 +1,8 @@
 // elementwise.hip — the small ops of reference src/ops.zig as standalone HIP kernels (op tier),
 // plus the decode-step head kernel of the model tier.  All are HBM/latency bound; loads are
 // 16 B per lane where the layout allows.
+#include <algorithm>
+
 #include "zg_kernels.h"
 
 namespace zg {
@@ -373,112 +375,115 @@ __global__ __launch_bounds__(512) void embed_step_kernel(const EmbedArgs a) {
 }
 
 // softmax(x / temp) and the weighted draw of GPT.sample (src/main.zig:200-206; std.rand weightedIndex: the first index whose
-// running sum exceeds u x total) for ONE row by a workgroup of 1024 lanes.  Every global access is coalesced (the first version
-// gave each lane a contiguous chunk of 50 logits — 1024 scattered streams — and scanned 1024 partial sums on one lane: ~100 us per
-// row at V = 50257).  The running sum keeps index order at the level that decides the draw: a wave sums SEGMENTS of 64 consecutive
-// elements (786 at V = 50257), one wave walks the segment sums in order — 64 lanes x consecutive runs of segments, a wave scan
-// over the lanes, the owning lane walks its run — and the segment that holds the point is scanned lane by lane.  Sums inside a
-// segment and over lanes are tree-shaped: the draw can differ from a strictly left-to-right sum only where u x total lies within
-// rounding (~1e-7) of a boundary.  WRITE: leave the probabilities in x, as the reference leaves them in state.logits.
-// Returns the draw (every lane); NaN probabilities (no interval holds the point) give the last index.  vocab <= 64 x 4096.
-template <bool WRITE>
-__device__ __forceinline__ int sample_row(float* x, int vocab, float inv_temp, float u, float* s_red, float* s_seg, int* s_pick) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float mx = -3.0e38f;
-    for (int i = tid; i < vocab; i += 1024) mx = fmaxf(mx, x[i] * inv_temp);
-    mx = block_allmax(mx, s_red);
-    const int nseg = (vocab + 63) >> 6;
-    float wsum = 0.0f;
-    for (int seg = wave; seg < nseg; seg += 16) {
-        const int i = seg * 64 + lane;
-        const float e = i < vocab ? __expf(x[i] * inv_temp - mx) : 0.0f;
-        const float sg = wave_allsum(e);
-        if (lane == 0) s_seg[seg] = sg;
-        wsum += sg;
-    }
-    const float total = block_allsum(lane == 0 ? wsum : 0.0f, s_red);  // (also the barrier behind s_seg)
-    const float inv = 1.0f / total;
-    if (tid == 0) *s_pick = vocab - 1;
+// running sum exceeds u x total), in three small kernels behind lm_head.  History: one workgroup per row with a contiguous chunk of
+// 50 logits per lane and a 1024-step serial scan (~100 us per row at V = 50257); then one workgroup with coalesced passes and
+// segment sums (28 us: a single CU has ~100 cache lines in flight against ~2 us of memory-side latency for 1600 lines of logits
+// that another XCD's lm_head just wrote).  Now:
+//   sample_seg_kernel   many workgroups: the row maximum comes from lm_head's argmax partials (no pass over the logits), every
+//                       wave sums e = exp(x / temp - max) over SEGMENTS of 64 consecutive elements (786 at V = 50257)
+//   sample_pick_kernel  one wave per row walks the segment sums IN INDEX ORDER (64 lanes x consecutive runs of segments, a scan
+//                       over the lanes, the owning lane walks its run), then scans the 64 elements of the segment that holds
+//                       u x total lane by lane.  Sums inside a segment and over lanes are tree-shaped: the draw can differ from a
+//                       strictly left-to-right sum only where u x total lies within rounding (~1e-7) of a boundary.
+//   sample_probs_kernel (only when the caller wants them) leaves the probabilities in the logits row, as the reference does.
+// NaN probabilities (no interval holds the point) give the last index.  vocab <= 64 x 4096.
+constexpr int kSegMax = 4096;  // segment sums per row; [kSegMax] = the row maximum / temp, [kSegMax + 1] = the total
+
+__global__ __launch_bounds__(256) void sample_seg_kernel(const float* __restrict__ logits, int vocab, const SampleParams* params, float inv_temp_arg,
+                                                         const float* __restrict__ part_val, int n_part, int part_stride, float* __restrict__ seg_out) {
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const float inv_temp = params ? params->inv_temp : inv_temp_arg;
+    const float* x = logits + (size_t)b * vocab;
+    float* so = seg_out + (size_t)b * (kSegMax + 2);
+    float mxr = -3.0e38f;  // max of the row = max of the per-workgroup maxima lm_head's argmax epilogue left (EPI_ARGMAX)
+    for (int p = tid; p < n_part; p += 256) mxr = fmaxf(mxr, part_val[(size_t)b * part_stride + p]);
+    mxr = wave_allmax(mxr);
+    if (lane == 0) s_red[wave] = mxr;
     __syncthreads();
-    if (wave == 0) {
-        const float point = u * total;
-        const int run = (nseg + 63) >> 6, s0 = lane * run, s1 = min(s0 + run, nseg);
-        float local = 0.0f;
-        for (int k = s0; k < s1; ++k) local += s_seg[k];
-        float incl = local;  // inclusive scan over the lanes, in lane order
+    const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])) * inv_temp;
+    const int nseg = (vocab + 63) >> 6;
+    for (int sg = blockIdx.x * 4 + wave; sg < nseg; sg += gridDim.x * 4) {
+        const int i = sg * 64 + lane;
+        const float e = i < vocab ? __expf(x[i] * inv_temp - mx) : 0.0f;
+        const float t = wave_allsum(e);
+        if (lane == 0) so[sg] = t;
+    }
+    if (blockIdx.x == 0 && tid == 0) so[kSegMax] = mx;
+}
+
+__global__ __launch_bounds__(64) void sample_pick_kernel(const float* __restrict__ logits, int vocab, const SampleParams* params, float inv_temp_arg,
+                                                         const float* __restrict__ u_arr, const StepCtrl* ctrl, float* __restrict__ seg_io,
+                                                         int* __restrict__ token_out) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const float inv_temp = params ? params->inv_temp : inv_temp_arg;
+    const float* x = logits + (size_t)b * vocab;
+    float* so = seg_io + (size_t)b * (kSegMax + 2);
+    float u;
+    if (u_arr) u = u_arr[b];
+    else {  // the counter PRNG of (seed, sequence length of the step whose logits these are, sequence): as zg_gpt_sample derives it on the host
+        unsigned long long z = params->seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)ctrl->seq_len * 0xD1B54A32D192ED03ULL + (unsigned long long)b + 1ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-08f;
+    }
+    const int nseg = (vocab + 63) >> 6;
+    const int run = (nseg + 63) >> 6, s0 = lane * run, s1 = min(s0 + run, nseg);
+    const float mx = so[kSegMax];
+    float local = 0.0f;
+    for (int k = s0; k < s1; ++k) local += so[k];
+    float incl = local;  // inclusive scan over the lanes, in lane order
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const float total = __shfl(incl, 63, 64);
+    const float point = u * total;
+    int pick = vocab - 1;
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(s0 < s1 && point < incl);
+    if (hit != 0ull) {
+        const int owner = __builtin_ctzll(hit);
+        int sg = 0;
+        float before = 0.0f;
+        if (lane == owner) {  // the owning lane walks its run of segments
+            before = incl - local;
+            sg = s1 - 1;
+            for (int k = s0; k < s1; ++k) {
+                const float v = so[k];
+                if (point < before + v) {
+                    sg = k;
+                    break;
+                }
+                before += v;
+            }
+        }
+        sg = __shfl(sg, owner, 64);
+        before = __shfl(before, owner, 64);
+        const int i = sg * 64 + lane;
+        float c = i < vocab ? __expf(x[i] * inv_temp - mx) : 0.0f;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const float up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
+            const float up = __shfl_up(c, off, 64);
+            if (lane >= off) c += up;
         }
-        const unsigned long long hit = __builtin_amdgcn_ballot_w64(s0 < s1 && point < incl);
-        if (hit != 0ull) {
-            const int owner = __builtin_ctzll(hit);
-            // the owning lane walks its run of segments; all lanes follow the same scalar path afterwards
-            int seg = 0;
-            float before = 0.0f;
-            if (lane == owner) {
-                before = incl - local;
-                seg = s1 - 1;
-                for (int k = s0; k < s1; ++k) {
-                    if (point < before + s_seg[k]) {
-                        seg = k;
-                        break;
-                    }
-                    before += s_seg[k];
-                }
-            }
-            seg = __shfl(seg, owner, 64);
-            before = __shfl(before, owner, 64);
-            const int i = seg * 64 + lane;
-            float e = 0.0f;
-            if (i < vocab) e = __expf(x[i] * inv_temp - mx);  // (x still holds the logits: the probabilities are written last)
-            float c = e;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float up = __shfl_up(c, off, 64);
-                if (lane >= off) c += up;
-            }
-            const unsigned long long in = __builtin_amdgcn_ballot_w64(i < vocab && point < before + c);
-            // (rounding between the segment sum and its lane-by-lane scan can leave the point just past the last lane: that lane then)
-            const int l = in != 0ull ? __builtin_ctzll(in) : min(63, vocab - 1 - seg * 64);
-            if (lane == 0) *s_pick = seg * 64 + l;
-        }
+        const unsigned long long in = __builtin_amdgcn_ballot_w64(i < vocab && point < before + c);
+        // (rounding between the segment sum and its lane-by-lane scan can leave the point just past the last lane: that lane then)
+        pick = sg * 64 + (in != 0ull ? __builtin_ctzll(in) : min(63, vocab - 1 - sg * 64));
     }
-    __syncthreads();
-    if (WRITE)  // every lane rewrites only elements it alone reads here: no ordering between lanes needed
-        for (int i = tid; i < vocab; i += 1024) x[i] = __expf(x[i] * inv_temp - mx) * inv;
-    return *s_pick;
+    if (lane == 0) {
+        token_out[b] = pick;
+        so[kSegMax + 1] = total;
+    }
 }
 
-// Sampler tail of GPT.sample (src/main.zig:200-206): one workgroup per sequence, in place on its logits
-// row: p = softmax(logits / temp); token = first index whose running sum of p exceeds u * sum(p).
-__global__ __launch_bounds__(1024) void sample_kernel(float* logits, int vocab, float inv_temp, const float* u,
-                                                      int* token_out) {
-    __shared__ float s_red[16];
-    __shared__ float s_seg[4096];
-    __shared__ int s_pick;
-    const int pick = sample_row<true>(logits + (size_t)blockIdx.x * vocab, vocab, inv_temp, u[blockIdx.x], s_red, s_seg, &s_pick);
-    if (threadIdx.x == 0) token_out[blockIdx.x] = pick;
-}
-
-// The same tail inside a captured decode step (zg_gpt_generate_sample_*): temperature and seed from device memory, the uniform
-// of (sequence, position) from the counter PRNG zg_gpt_sample uses for uniforms == NULL (splitmix64 finaliser, 24 random bits),
-// the atomicMin target armed by the kernel itself.  One workgroup per sequence, in place on its logits row.
-__global__ __launch_bounds__(1024) void sample_step_kernel(float* logits, int vocab, const SampleParams* params, const StepCtrl* ctrl, int* token_out) {
-    __shared__ float s_red[16];
-    __shared__ float s_seg[4096];
-    __shared__ int s_pick;
-    // u of (seed, sequence length of the step whose logits these are, sequence): as zg_gpt_sample derives it on the host
-    unsigned long long z = params->seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)ctrl->seq_len * 0xD1B54A32D192ED03ULL + (unsigned long long)blockIdx.x + 1ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z ^= z >> 31;
-    const float u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-08f;
-    // (no probabilities written back: nobody reads the logits of a step in the loop; the draw itself is computed before that
-    // pass in zg_gpt_sample's kernel too — same tokens)
-    const int pick = sample_row<false>(logits + (size_t)blockIdx.x * vocab, vocab, params->inv_temp, u, s_red, s_seg, &s_pick);
-    if (threadIdx.x == 0) token_out[blockIdx.x] = pick;
+__global__ __launch_bounds__(256) void sample_probs_kernel(float* logits, int vocab, float inv_temp, const float* __restrict__ seg_io) {
+    const int b = blockIdx.y;
+    float* x = logits + (size_t)b * vocab;
+    const float* so = seg_io + (size_t)b * (kSegMax + 2);
+    const float mx = so[kSegMax], inv = 1.0f / so[kSegMax + 1];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vocab; i += gridDim.x * 256) x[i] = __expf(x[i] * inv_temp - mx) * inv;
 }
 
 inline int grid_for(size_t n, int block = 256, int cap = 2048) {
@@ -642,19 +647,33 @@ int launch_split3(const float* in, size_t rows, int K, bf16_t* out, hipStream_t 
     return ZG_OK;
 }
 
-int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s) {
-    ZG_REQUIRE(vocab >= 1 && vocab <= 64 * 4096, ZG_ERR_UNSUPPORTED, "sampler: vocabulary of %d beyond 262144", vocab);
-    hipLaunchKernelGGL(sample_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, 1.0f / temp, u, token_out);
+static int sample_launches(float* logits, int batch, int vocab, const SampleParams* params, float inv_temp, const float* u, const StepCtrl* ctrl,
+                           const float* part_val, int n_part, int part_stride, float* seg_ws, int* token_out, bool write_probs, hipStream_t s) {
+    ZG_REQUIRE(vocab >= 1 && vocab <= 64 * kSegMax, ZG_ERR_UNSUPPORTED, "sampler: vocabulary of %d beyond %d", vocab, 64 * kSegMax);
+    ZG_REQUIRE(part_val && n_part >= 1 && seg_ws && token_out, ZG_ERR_ARG, "sampler: missing argmax partials / workspace");
+    const int nseg = (vocab + 63) / 64, nb = std::min(128, (nseg + 3) / 4);
+    hipLaunchKernelGGL(sample_seg_kernel, dim3(nb, batch), dim3(256), 0, s, logits, vocab, params, inv_temp, part_val, n_part, part_stride, seg_ws);
     ZG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sample_pick_kernel, dim3(batch), dim3(64), 0, s, logits, vocab, params, inv_temp, u, ctrl, seg_ws, token_out);
+    ZG_HIP(hipGetLastError());
+    if (write_probs) {
+        hipLaunchKernelGGL(sample_probs_kernel, dim3(std::min(256, (vocab + 255) / 256), batch), dim3(256), 0, s, logits, vocab, inv_temp, seg_ws);
+        ZG_HIP(hipGetLastError());
+    }
     return ZG_OK;
 }
 
-int launch_sample_step(float* logits, int batch, int vocab, const SampleParams* params, const StepCtrl* ctrl, int* token_out, hipStream_t s) {
-    ZG_REQUIRE(vocab >= 1 && vocab <= 64 * 4096, ZG_ERR_UNSUPPORTED, "sampler: vocabulary of %d beyond 262144", vocab);
-    hipLaunchKernelGGL(sample_step_kernel, dim3(batch), dim3(1024), 0, s, logits, vocab, params, ctrl, token_out);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
+int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, const float* part_val, int n_part, int part_stride, float* seg_ws,
+                  int* token_out, bool write_probs, hipStream_t s) {
+    return sample_launches(logits, batch, vocab, nullptr, 1.0f / temp, u, nullptr, part_val, n_part, part_stride, seg_ws, token_out, write_probs, s);
 }
+
+int launch_sample_step(float* logits, int batch, int vocab, const SampleParams* params, const StepCtrl* ctrl, const float* part_val, int n_part,
+                       int part_stride, float* seg_ws, int* token_out, hipStream_t s) {
+    return sample_launches(logits, batch, vocab, params, 0.0f, nullptr, ctrl, part_val, n_part, part_stride, seg_ws, token_out, false, s);
+}
+
+size_t sample_workspace_floats(int batch) { return (size_t)batch * (kSegMax + 2); }
 
 int launch_embed_step(const EmbedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(embed_step_kernel, dim3(1), dim3(a.batch > 4 ? 512 : 256), 0, s, a);  // one wave per sequence

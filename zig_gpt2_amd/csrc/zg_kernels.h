@@ -253,7 +253,11 @@ int launch_attn_prefill(const float* qkv, bf16_t* out, int B, int P, int E, int 
                         const float* v_cache_or_null, int ctx, hipStream_t s, int force_tiles = 0);  // force_tiles: key tiles per workgroup (tests)
 
 // GPT.sample tail: in-place softmax(logits / temp) per sequence + inverse-CDF draw with uniform u[b].
-int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, int* token_out, hipStream_t s);
+// part_val / n_part / part_stride: the per-workgroup maxima lm_head's argmax epilogue left (the row maximum without a pass over the
+// logits); seg_ws: sample_workspace_floats(batch) floats; write_probs: leave softmax(logits / temp) in the logits rows
+int launch_sample(float* logits, int batch, int vocab, float temp, const float* u, const float* part_val, int n_part, int part_stride, float* seg_ws,
+                  int* token_out, bool write_probs, hipStream_t s);
+size_t sample_workspace_floats(int batch);
 
 // Decode-step head kernel: token selection (+ argmax finalisation of the previous step) and
 // x = wte[token] + wpe[pos].
@@ -295,7 +299,8 @@ struct SampleParams {
     unsigned pad;
     unsigned long long seed;
 };
-int launch_sample_step(float* logits, int batch, int vocab, const SampleParams* params, const StepCtrl* ctrl, int* token_out, hipStream_t s);
+int launch_sample_step(float* logits, int batch, int vocab, const SampleParams* params, const StepCtrl* ctrl, const float* part_val, int n_part,
+                       int part_stride, float* seg_ws, int* token_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ multi-GPU (dist.hip)
 int dist_broadcast(void* buf, size_t bytes, int root, hipStream_t s);  // in place, over the communicator of zg_dist_init
