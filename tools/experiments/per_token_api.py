@@ -31,5 +31,13 @@ def fwd_argmax(T, tok):
     m.forward(T, [tok], want_logits=False)
     return int(m.argmax()[0])
 res["forward_plus_argmax_call_tok_s"] = loop(fwd_argmax)
+def fwd_only(T, tok):
+    m.forward(T, [tok], want_logits=False)
+    return tok
+res["forward_no_copy_tok_s"] = loop(fwd_only)
+def fwd_nologits(T, tok):
+    m.forward(T, [tok], compute_logits=False)
+    return tok
+res["forward_without_lm_head_tok_s"] = loop(fwd_nologits)
 t0 = time.perf_counter(); m.generate([[11]], n); res["generate_greedy_tok_s"] = round(n / (time.perf_counter() - t0), 1)
 print(json.dumps(res))
